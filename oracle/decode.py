@@ -1,0 +1,170 @@
+"""Oracle: FCOS locations, per-level decode, class-aware NMS, top-k keep, postprocess.
+TEST INFRASTRUCTURE.  fp32 torch/numpy CPU.
+
+Sylph-owned arithmetic followed (paths relative to /root/reference):
+  * sylph/modeling/meta_fcos/fcos.py:270-282                 compute_locations (formula in the
+    docstring :272; body is AdelaiDet adet/utils/comm.py compute_locations, restated)
+  * sylph/modeling/meta_fcos/fcos_outputs.py:743-812         predict_proposals
+  * sylph/modeling/meta_fcos/fcos_outputs.py:904-1008        forward_for_single_feature_map
+  * sylph/modeling/meta_fcos/fcos_outputs.py:1010-1028       select_over_all_levels
+  * sylph/modeling/meta_arch/meta_one_stage_detector.py:288-296  postprocess loop
+Third-party arithmetic restated (not under /root/reference; parity unpinned by the reference):
+  * adet.layers.ml_nms -> detectron2.layers.batched_nms -> torchvision.ops.nms: greedy NMS per
+    class, boxes visited in descending score order, suppress when IoU > thresh
+    (IoU = inter / (area_i + area_j - inter), no +1), result sorted by descending score.
+    Restated as the exact per-class form (torchvision ``_batched_nms_vanilla``); the
+    coordinate-offset variant differs only by fp32 rounding of the offset boxes.
+  * adet detector_postprocess -> detectron2 detector_postprocess: scale boxes by
+    (out_w / img_w, out_h / img_h), clip to the output size, drop empty boxes.
+
+Determinism contract (shared with the HIP path; the reference leaves these unspecified):
+  * candidates are ordered (level, location, class) -- the ``nonzero`` order of
+    fcos_outputs.py:967-969 concatenated over levels (:808-809);
+  * pre-NMS top-k (``topk(sorted=False)``, :980-982) keeps the k largest ``cls*ctr`` values, ties
+    at the k-th value resolved towards the lower (location, class) index, order preserved;
+  * NMS visits boxes by descending ``scores`` (= sqrt(cls*ctr)), ties by ascending candidate index.
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def compute_locations(h: int, w: int, stride: int) -> torch.Tensor:
+    """(h*w, 2) fp32, x = j*s + s//2, y = i*s + s//2, row-major over (i, j).  fcos.py:270-282."""
+    sx = torch.arange(0, w * stride, step=stride, dtype=torch.float32)
+    sy = torch.arange(0, h * stride, step=stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    return torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + stride // 2
+
+
+def decode_level(locations: torch.Tensor, logits: torch.Tensor, reg: torch.Tensor, ctr: torch.Tensor,
+                 iou: torch.Tensor, pre_nms_thresh: float = 0.05, pre_nms_topk: int = 1000,
+                 thresh_with_ctr: bool = False, box_quality: Sequence[str] = ("ctrness",)) -> List[Dict]:
+    """fcos_outputs.py:904-1008.  ``reg`` is already multiplied by the level stride (:786)."""
+    N, C, H, W = logits.shape
+    p = logits.permute(0, 2, 3, 1).reshape(N, -1, C).sigmoid()
+    box_reg = reg.view(N, 4, H, W).permute(0, 2, 3, 1).reshape(N, -1, 4)
+    c = ctr.view(N, 1, H, W).permute(0, 2, 3, 1).reshape(N, -1).sigmoid()
+    q = iou.view(N, 1, H, W).permute(0, 2, 3, 1).reshape(N, -1).sigmoid()
+    bq = sorted(box_quality)
+    if bq == ["ctrness"]:
+        quality = c[:, :, None]
+    elif bq == ["iou"]:
+        quality = q[:, :, None]
+    elif bq == ["ctrness", "iou"]:
+        quality = torch.sqrt(q[:, :, None] * c[:, :, None])
+    else:
+        raise NotImplementedError()
+    if thresh_with_ctr:
+        p = p * quality
+    cand = p > pre_nms_thresh
+    top_n = cand.reshape(N, -1).sum(1).clamp(max=pre_nms_topk)
+    if not thresh_with_ctr:
+        p = p * quality
+    results = []
+    for i in range(N):
+        vals = p[i][cand[i]]
+        nz = cand[i].nonzero()
+        loc_idx, cls_idx = nz[:, 0], nz[:, 1]
+        k = int(top_n[i])
+        if vals.numel() > k:
+            # deterministic top-k: k largest, ties -> lower index, original order kept
+            order = np.lexsort((np.arange(vals.numel()), -vals.numpy().astype(np.float64)))
+            sel = torch.from_numpy(np.sort(order[:k]))
+            vals, loc_idx, cls_idx = vals[sel], loc_idx[sel], cls_idx[sel]
+        r = box_reg[i][loc_idx]
+        l = locations[loc_idx]
+        boxes = torch.stack([l[:, 0] - r[:, 0], l[:, 1] - r[:, 1], l[:, 0] + r[:, 2], l[:, 1] + r[:, 3]], dim=1)
+        results.append({"pred_boxes": boxes, "scores": torch.sqrt(vals), "pred_classes": cls_idx,
+                        "locations": l, "loc_index": loc_idx})
+    return results
+
+
+def nms_per_class(boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray, thresh: float) -> np.ndarray:
+    """Greedy class-aware NMS (torchvision nms arithmetic, fp32).  Returns kept indices in
+    descending-score order (ties: ascending index)."""
+    n = boxes.shape[0]
+    if n == 0:
+        return np.zeros((0,), dtype=np.int64)
+    boxes = boxes.astype(np.float32)
+    order = np.lexsort((np.arange(n), -scores.astype(np.float64)))
+    x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    areas = ((x2 - x1) * (y2 - y1)).astype(np.float32)
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    for oi in range(n):
+        i = order[oi]
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        rest = order[oi + 1:]
+        rest = rest[(~suppressed[rest]) & (classes[rest] == classes[i])]
+        if rest.size == 0:
+            continue
+        xx1 = np.maximum(x1[i], x1[rest])
+        yy1 = np.maximum(y1[i], y1[rest])
+        xx2 = np.minimum(x2[i], x2[rest])
+        yy2 = np.minimum(y2[i], y2[rest])
+        w = np.maximum(np.float32(0), (xx2 - xx1).astype(np.float32))
+        h = np.maximum(np.float32(0), (yy2 - yy1).astype(np.float32))
+        inter = (w * h).astype(np.float32)
+        union = ((areas[i] + areas[rest]).astype(np.float32) - inter).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = (inter / union).astype(np.float32)
+        suppressed[rest[ovr > np.float32(thresh)]] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def select_over_all_levels(inst: Dict, nms_thresh: float = 0.6, post_nms_topk: int = 100) -> Dict:
+    """fcos_outputs.py:1010-1028: ml_nms, then keep scores >= k-th largest (ties kept)."""
+    if nms_thresh > 0:
+        keep = nms_per_class(inst["pred_boxes"].numpy(), inst["scores"].numpy(),
+                             inst["pred_classes"].numpy(), nms_thresh)
+        keep = torch.from_numpy(keep)
+        inst = {k: v[keep] for k, v in inst.items()}
+        inst["nms_keep"] = keep
+    n = inst["scores"].numel()
+    if n > post_nms_topk > 0:
+        thr, _ = torch.kthvalue(inst["scores"], n - post_nms_topk + 1)
+        sel = torch.nonzero(inst["scores"] >= thr.item()).squeeze(1)
+        inst = {k: v[sel] for k, v in inst.items()}
+    return inst
+
+
+def predict_proposals(logits, regs, ctrs, ious, strides=(8, 16, 32, 64, 128), pre_nms_thresh=0.05,
+                      pre_nms_topk=1000, nms_thresh=0.6, post_nms_topk=100, thresh_with_ctr=False,
+                      box_quality=("ctrness",)) -> List[Dict]:
+    """fcos_outputs.py:743-812.  Per image dict: pred_boxes, scores, pred_classes, locations,
+    fpn_levels (+ loc_index, cand_index = index into the concatenated pre-NMS candidate list)."""
+    per_level = []
+    for level, (o, r, c, q) in enumerate(zip(logits, regs, ctrs, ious)):
+        h, w = o.shape[-2:]
+        loc = compute_locations(h, w, strides[level])
+        res = decode_level(loc, o, r * strides[level], c, q, pre_nms_thresh, pre_nms_topk,
+                           thresh_with_ctr, box_quality)
+        for d in res:
+            d["fpn_levels"] = torch.full((d["scores"].numel(),), level, dtype=torch.long)
+        per_level.append(res)
+    out = []
+    for i in range(logits[0].shape[0]):
+        cat = {k: torch.cat([lv[i][k] for lv in per_level], dim=0) for k in per_level[0][i].keys()}
+        cat["cand_index"] = torch.arange(cat["scores"].numel())
+        out.append(select_over_all_levels(cat, nms_thresh, post_nms_topk))
+    return out
+
+
+def detector_postprocess(inst: Dict, image_size: Tuple[int, int], out_h: int, out_w: int) -> Dict:
+    """detectron2/adet detector_postprocess restated; call site meta_one_stage_detector.py:292-295."""
+    sx, sy = out_w / image_size[1], out_h / image_size[0]
+    b = inst["pred_boxes"].clone()
+    b[:, 0::2] *= sx
+    b[:, 1::2] *= sy
+    b[:, 0].clamp_(min=0, max=out_w)
+    b[:, 1].clamp_(min=0, max=out_h)
+    b[:, 2].clamp_(min=0, max=out_w)
+    b[:, 3].clamp_(min=0, max=out_h)
+    keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+    res = {k: v[keep] for k, v in inst.items()}
+    res["pred_boxes"] = b[keep]
+    return res

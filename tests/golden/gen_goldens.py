@@ -1,0 +1,223 @@
+"""Generate golden vectors by running the REFERENCE's own Sylph modules (imported from
+/root/reference through tests/golden/ref_shim.py) on seeded inputs.  Run in the build container:
+
+    python tests/golden/gen_goldens.py
+
+Writes tests/golden/*.npz (inputs + expected outputs; data only).  The reference never travels:
+the GPU box replays these fixtures against the oracle and the HIP path.
+Weights are NOT stored (too large); they are regenerated from oracle.weights seeds and guarded by
+a checksum stored in each fixture.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sylph-few-shot-detection_amd"))
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+from oracle import weights as W  # noqa: E402
+from sylph_amd.config import get_default_cfg  # noqa: E402
+
+
+def checksum(sd, prefix):
+    return float(sum(v.double().abs().sum() for k, v in sorted(sd.items()) if k.startswith(prefix)))
+
+
+def make_cfg(lvis=False):
+    cfg = get_default_cfg()
+    cfg.MODEL.DEVICE = "cpu"
+    ml = cfg.MODEL.META_LEARN
+    ml.EPISODIC_LEARNING = True
+    cg = ml.CODE_GENERATOR
+    cg.CONV_L2_NORM = True
+    cg.TOWER_LAYERS = [["GN", "ReLU"], ["GN", "ReLU"]]
+    cg.CLS_LAYER = ["", "", 1]
+    cg.BIAS_LAYER = ["", "", 1]
+    cfg.MODEL.PROPOSAL_GENERATOR.FREEZE_BBOX_BRANCH = True
+    cfg.MODEL.FCOS.NUM_CLASSES = 60
+    if lvis:
+        cg.BIAS_L2_NORM = True
+        cfg.MODEL.FCOS.NUM_CLASSES = 866
+        cfg.MODEL.FCOS.POST_NMS_TOPK_TEST = 300
+    return cfg
+
+
+def load_prefixed(module, sd, prefix):
+    sub = {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+    missing, unexpected = module.load_state_dict(sub, strict=False)
+    assert not unexpected, unexpected
+    return missing
+
+
+def feature_pyramid(B, h, w, seed, scale=1.0):
+    """Features are multiples of 1/32 in [-4, 4) so fixtures can store them as int8."""
+    g = torch.Generator().manual_seed(seed)
+    feats = []
+    for s in (8, 16, 32, 64, 128):
+        hh, ww = -(-h // s), -(-w // s)
+        q = torch.randint(-128, 128, (B, 256, hh, ww), generator=g, dtype=torch.int16)
+        feats.append(q.float() / 32.0 * scale)
+    return feats
+
+
+def q8(t):
+    q = (t * 32.0).round()
+    assert torch.equal(q / 32.0, t) and q.abs().max() <= 128
+    return q.to(torch.int8).numpy()
+
+
+def inst_to_np(inst, prefix):
+    out = {}
+    for k, v in inst.get_fields().items():
+        t = v.tensor if hasattr(v, "tensor") else v
+        out[f"{prefix}_{k}"] = t.detach().numpy()
+    return out
+
+
+def gen_head_decode():
+    from sylph.modeling.meta_fcos.fcos import MetaFCOS
+    from ref_shim import ShapeSpec
+    cfg = make_cfg()
+    sd = W.head_state_dict(seed=1, num_classes=60)
+    shapes = {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(3, 8)}
+    model = MetaFCOS(cfg, shapes).eval()
+    load_prefixed(model, sd, "proposal_generator")
+    H, Wd, B = 128, 160, 2
+    feats = feature_pyramid(B, H, Wd, seed=11)
+    out = {"weights_checksum": checksum(sd, "proposal_generator"), "image_size": np.array([H, Wd])}
+    for l, f in enumerate(feats):
+        out[f"feat{l}_q8"] = q8(f)
+    image_sizes = [(H, Wd - 7), (H - 5, Wd)]
+    out["image_sizes"] = np.array(image_sizes)
+    with torch.no_grad():
+        for n, cscale, thr in ((1, 2.5, 0.05), (5, 2.0, 0.05), (20, 1.5, 0.05), (20, 2.5, 0.011)):
+            tag = f"n{n}_t{int(thr * 1000)}"
+            codes = W.synthetic_codes(n, seed=30 + n, scale=cscale)
+            out[f"{tag}_cls_conv"] = codes["cls_conv"].numpy()
+            out[f"{tag}_cls_bias"] = codes["cls_bias"].numpy()
+            logits, reg, ctr, iou, _, _ = model.fcos_head(feats, None, False, codes)
+            for l in range(5):
+                out[f"{tag}_logits{l}"] = logits[l].numpy()
+                if n == 1:
+                    out[f"reg{l}"] = reg[l].numpy()
+                    out[f"ctr{l}"] = ctr[l].numpy()
+                    out[f"iou{l}"] = iou[l].numpy()
+            model.fcos_outputs.pre_nms_thresh_test = thr
+            locations = model.compute_locations(feats)
+            props = model.fcos_outputs.predict_proposals(logits, reg, ctr, iou, locations, image_sizes, [])
+            for i, p in enumerate(props):
+                out.update(inst_to_np(p, f"{tag}_img{i}"))
+            out[f"{tag}_count"] = np.array([len(p) for p in props])
+            print("head/decode", tag, [len(p) for p in props])
+    np.savez_compressed(os.path.join(HERE, "g1_head_decode.npz"), **out)
+
+
+def gen_codegen():
+    from sylph.modeling.code_generator.code_generator import CodeGenerator
+    from ref_shim import Boxes, Instances
+    import sylph.modeling.code_generator.code_generator as cgmod
+    out = {}
+    sd = W.codegen_state_dict(seed=2)
+    out["weights_checksum"] = checksum(sd, "code_generator")
+    H, Wd = 192, 256
+    for lvis in (False, True):
+        cfg = make_cfg(lvis)
+        gen = CodeGenerator(cfg, 256, 5, cfg.MODEL.FCOS.FPN_STRIDES).eval()
+        load_prefixed(gen, sd, "code_generator")
+        tagc = "lvis" if lvis else "coco"
+        all_codes = []
+        for S in (1, 2, 5):
+            feats = feature_pyramid(S, H, Wd, seed=100 + S)
+            boxes = W.synthetic_boxes(S, H, Wd, seed=200 + S)
+            if S == 5:  # exercise levels 3..6 and boundary-touching boxes
+                boxes[0] = torch.tensor([4.0, 6.0, 60.0, 50.0])
+                boxes[1] = torch.tensor([0.0, 0.0, 255.0, 191.0])
+                boxes[2] = torch.tensor([60.5, 20.25, 250.75, 180.0])
+            insts = []
+            for i in range(S):
+                it = Instances((H, Wd))
+                it.gt_boxes = Boxes(boxes[i:i + 1])
+                it.gt_classes = torch.tensor([3])
+                insts.append(it)
+            with torch.no_grad():
+                code = gen(feats, insts)
+            tag = f"{tagc}_s{S}"
+            if not lvis:
+                for l, f in enumerate(feats):
+                    out[f"s{S}_feat{l}_q8"] = q8(f)
+                out[f"s{S}_boxes"] = boxes.numpy()
+            out[f"{tag}_cls_conv"] = code["cls_conv"].numpy()
+            out[f"{tag}_cls_bias"] = code["cls_bias"].numpy()
+            all_codes.append({"support_set_target": torch.tensor(len(all_codes)), "class_name": f"c{S}",
+                              "class_code": {k: v.clone() for k, v in code.items()}})
+            print("codegen", tag, code["cls_conv"].flatten()[:3], code["cls_bias"].flatten())
+        # normalisation (run_type meta_learn_normalize_code) + formatting
+        with torch.no_grad():
+            normed = gen(None, None, cls_norm=True, class_codes=all_codes)
+        for i, c in enumerate(normed):
+            out[f"{tagc}_norm{i}_cls_conv"] = c["class_code"]["cls_conv"].numpy()
+            out[f"{tagc}_norm{i}_cls_bias"] = c["class_code"]["cls_bias"].numpy()
+        from sylph.evaluation.meta_learn_evaluation import format_class_codes_shared
+        shuffled = [normed[2], normed[0], normed[1]]
+        fm = format_class_codes_shared(shuffled, "cpu")
+        out[f"{tagc}_fmt_cls_conv"] = fm["cls_conv"].numpy()
+        out[f"{tagc}_fmt_cls_bias"] = fm["cls_bias"].numpy()
+    np.savez_compressed(os.path.join(HERE, "g3_codegen.npz"), **out)
+
+
+def gen_reduce_condblock():
+    from sylph.modeling.code_generator.utils import reduce_class_code
+    from sylph.modeling.meta_fcos.head_utils import CondConvBlock
+    import sylph.modeling.code_generator.utils as u
+    import logging
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    chunks = []
+    # class 0: three chunks with weights summing to 1; class 1: two chunks summing to 0.7
+    for cid, wts in ((0, (0.5, 0.3, 0.2)), (1, (0.4, 0.3))):
+        for w in wts:
+            conv = torch.randn(1, 256, 1, 1, generator=g)
+            bias = torch.randn(1, 1, 1, 1, generator=g)
+            wn = torch.randn(1, 1, 1, 1, generator=g)
+            chunks.append({"support_set_target": cid, "class_name": f"k{cid}",
+                           "class_code": {"cls_conv": conv * w, "cls_bias": bias * w,
+                                          "cls_weight_norm": wn * w, "acc_weight": w}})
+    for i, c in enumerate(chunks):
+        out[f"chunk{i}_cid"] = np.array(c["support_set_target"])
+        for k, v in c["class_code"].items():
+            out[f"chunk{i}_{k}"] = np.asarray(v)
+    import copy
+    red = reduce_class_code(copy.deepcopy(chunks))
+    for r in red:
+        cid = r["support_set_target"]
+        for k, v in r["class_code"].items():
+            out[f"reduced{cid}_{k}"] = np.asarray(v)
+    # CondConvBlock 256 and 512 channels
+    feat = torch.randn(2, 256, 5, 6, generator=g)
+    for k in (1, 2):
+        blk = CondConvBlock(padding=0, weight_len=256 * k)
+        w = torch.randn(7, 256 * k, 1, 1, generator=g) * 0.1
+        b = torch.randn(7, generator=g)
+        with torch.no_grad():
+            y = blk(feat, w, b)
+        out[f"ccb{k}_w"], out[f"ccb{k}_b"], out[f"ccb{k}_y"] = w.numpy(), b.numpy(), y.numpy()
+    out["ccb_feat"] = feat.numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_reduce_condblock.npz"), **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    np.random.seed(0)
+    gen_head_decode()
+    gen_codegen()
+    gen_reduce_condblock()
+    print("done")

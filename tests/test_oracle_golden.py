@@ -1,0 +1,133 @@
+"""Pin the oracle against golden vectors produced by the reference itself
+(tests/golden/gen_goldens.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import codegen as CG
+from oracle import decode as D
+from oracle import episode as E
+from oracle import head as H
+from oracle import weights as W
+
+TOL = 2e-5
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _checksum(sd, prefix):
+    return float(sum(v.double().abs().sum() for k, v in sorted(sd.items()) if k.startswith(prefix)))
+
+
+def _feats(g, prefix="feat"):
+    return [torch.from_numpy(g[f"{prefix}{l}_q8"].astype(np.float32) / 32.0) for l in range(5)]
+
+
+@pytest.fixture(scope="module")
+def g1(golden_dir):
+    return _load(golden_dir, "g1_head_decode.npz")
+
+
+@pytest.fixture(scope="module")
+def head_sd(g1):
+    sd = W.head_state_dict(seed=1, num_classes=60)
+    assert abs(_checksum(sd, "proposal_generator") - float(g1["weights_checksum"])) < 1e-3
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["n1_t50", "n5_t50", "n20_t50", "n20_t11"])
+def test_head_logits_match_reference(g1, head_sd, tag):
+    feats = _feats(g1)
+    codes = {"cls_conv": torch.from_numpy(g1[f"{tag}_cls_conv"]), "cls_bias": torch.from_numpy(g1[f"{tag}_cls_bias"])}
+    logits, regs, ctrs, ious = H.fcos_head(feats, head_sd, codes)
+    for l in range(5):
+        np.testing.assert_allclose(logits[l].numpy(), g1[f"{tag}_logits{l}"], atol=TOL, rtol=TOL)
+    if tag == "n1_t50":
+        for l in range(5):
+            np.testing.assert_allclose(regs[l].numpy(), g1[f"reg{l}"], atol=TOL, rtol=TOL)
+            np.testing.assert_allclose(ctrs[l].numpy(), g1[f"ctr{l}"], atol=TOL, rtol=TOL)
+            np.testing.assert_allclose(ious[l].numpy(), g1[f"iou{l}"], atol=TOL, rtol=TOL)
+
+
+@pytest.mark.parametrize("tag,thr", [("n1_t50", 0.05), ("n5_t50", 0.05), ("n20_t50", 0.05), ("n20_t11", 0.011)])
+def test_decode_matches_reference(g1, head_sd, tag, thr):
+    """Decode + NMS + top-k keep on the REFERENCE's own head outputs."""
+    logits = [torch.from_numpy(g1[f"{tag}_logits{l}"]) for l in range(5)]
+    regs = [torch.from_numpy(g1[f"reg{l}"]) for l in range(5)]
+    ctrs = [torch.from_numpy(g1[f"ctr{l}"]) for l in range(5)]
+    ious = [torch.from_numpy(g1[f"iou{l}"]) for l in range(5)]
+    props = D.predict_proposals(logits, regs, ctrs, ious, pre_nms_thresh=thr)
+    for i, p in enumerate(props):
+        pre = f"{tag}_img{i}"
+        assert p["scores"].numel() == int(g1[f"{tag}_count"][i])
+        np.testing.assert_array_equal(p["pred_classes"].numpy(), g1[f"{pre}_pred_classes"])
+        np.testing.assert_array_equal(p["fpn_levels"].numpy(), g1[f"{pre}_fpn_levels"])
+        np.testing.assert_array_equal(p["locations"].numpy(), g1[f"{pre}_locations"])
+        np.testing.assert_allclose(p["scores"].numpy(), g1[f"{pre}_scores"], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(p["pred_boxes"].numpy(), g1[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def g3(golden_dir):
+    return _load(golden_dir, "g3_codegen.npz")
+
+
+@pytest.fixture(scope="module")
+def cg_sd(g3):
+    sd = W.codegen_state_dict(seed=2)
+    assert abs(_checksum(sd, "code_generator") - float(g3["weights_checksum"])) < 1e-3
+    return sd
+
+
+@pytest.mark.parametrize("lvis", [False, True])
+@pytest.mark.parametrize("S", [1, 2, 5])
+def test_codegen_matches_reference(g3, cg_sd, lvis, S):
+    feats = _feats(g3, f"s{S}_feat")
+    boxes = torch.from_numpy(g3[f"s{S}_boxes"])
+    code = CG.code_generator(feats, boxes, cg_sd, bias_l2_norm=lvis)
+    tag = f"{'lvis' if lvis else 'coco'}_s{S}"
+    assert code["cls_conv"].shape == (1, 256, 1, 1) and code["cls_bias"].shape == (1, 1, 1, 1)
+    np.testing.assert_allclose(code["cls_conv"].numpy(), g3[f"{tag}_cls_conv"], atol=TOL, rtol=TOL)
+    np.testing.assert_allclose(code["cls_bias"].numpy(), g3[f"{tag}_cls_bias"], atol=TOL, rtol=TOL)
+
+
+@pytest.mark.parametrize("tagc", ["coco", "lvis"])
+def test_normalize_and_format_match_reference(g3, cg_sd, tagc):
+    codes = []
+    for i, S in enumerate((1, 2, 5)):
+        codes.append({"support_set_target": torch.tensor(i), "class_name": f"c{S}",
+                      "class_code": {"cls_conv": torch.from_numpy(g3[f"{tagc}_s{S}_cls_conv"]),
+                                     "cls_bias": torch.from_numpy(g3[f"{tagc}_s{S}_cls_bias"])}})
+    normed = CG.forward_normalize_code(codes, cg_sd)
+    for i, c in enumerate(normed):
+        np.testing.assert_allclose(c["class_code"]["cls_conv"].numpy(), g3[f"{tagc}_norm{i}_cls_conv"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(c["class_code"]["cls_bias"].numpy(), g3[f"{tagc}_norm{i}_cls_bias"], atol=TOL, rtol=TOL)
+        assert abs(float(c["class_code"]["cls_conv"].flatten().norm()) - 1.3) < 1e-4  # conv_scale * unit L2
+    fm = E.format_class_codes_shared([normed[2], normed[0], normed[1]])
+    assert fm["cls_conv"].shape == (3, 256, 1, 1) and fm["cls_bias"].shape == (3,)
+    np.testing.assert_allclose(fm["cls_conv"].numpy(), g3[f"{tagc}_fmt_cls_conv"], atol=TOL, rtol=TOL)
+    np.testing.assert_allclose(fm["cls_bias"].numpy(), g3[f"{tagc}_fmt_cls_bias"], atol=TOL, rtol=TOL)
+
+
+def test_reduce_and_condblock_match_reference(golden_dir):
+    g = _load(golden_dir, "g5_reduce_condblock.npz")
+    chunks = []
+    for i in range(5):
+        cc = {k: torch.as_tensor(g[f"chunk{i}_{k}"]) for k in ("cls_conv", "cls_bias", "cls_weight_norm")}
+        cc["acc_weight"] = float(g[f"chunk{i}_acc_weight"])
+        chunks.append({"support_set_target": int(g[f"chunk{i}_cid"]), "class_name": "k", "class_code": cc})
+    red = E.gather_class_code([chunks[:2], chunks[2:]], reduce=True)
+    assert len(red) == 2
+    for r in red:
+        cid = r["support_set_target"]
+        assert "acc_weight" not in r["class_code"]
+        for k, v in r["class_code"].items():
+            np.testing.assert_allclose(np.asarray(v), g[f"reduced{cid}_{k}"], atol=1e-6, rtol=1e-6)
+    feat = torch.from_numpy(g["ccb_feat"])
+    for k in (1, 2):
+        y = H.cond_conv_block(feat, torch.from_numpy(g[f"ccb{k}_w"]), torch.from_numpy(g[f"ccb{k}_b"]))
+        np.testing.assert_allclose(y.numpy(), g[f"ccb{k}_y"], atol=TOL, rtol=TOL)
