@@ -1,0 +1,134 @@
+/* libsylph_hip.so -- C ABI of the MI355X-native Sylph few-shot detection inference path.
+ *
+ * The reference (facebookresearch/sylph-few-shot-detection) is 100 % Python and has no FFI: its
+ * "ABI" for this path is nn.Module.forward.  Each entry point below names the reference call it
+ * replaces (paths relative to the reference root).  Plain pointers and sizes only; device pointers
+ * are raw HIP device addresses (e.g. torch.Tensor.data_ptr()), the caller owns every buffer it
+ * passes in, the library owns only the weights and workspace held by the context.
+ *
+ * Conventions
+ *   - return value: 0 on success, non-zero on error; sylph_last_error() gives the message.
+ *   - one context per process / GPU (the reference runs one process per GPU,
+ *     tools/train_net.py:98-106); kernels are enqueued on the stream given to sylph_set_stream
+ *     (default: the NULL stream).  No internal threads.  Calls do not synchronise unless stated.
+ *   - "current batch": sylph_preprocess / sylph_import_pyramid select the batch (B, H, W) the
+ *     following stage calls operate on.
+ */
+#ifndef SYLPH_HIP_H
+#define SYLPH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sylph_ctx sylph_ctx;
+
+enum { SYLPH_F32 = 0, SYLPH_BF16 = 1 };
+
+/* Subset of the yacs config the path reads (sylph/runner/adet_configs.py:25-61,
+ * sylph/runner/default_configs.py:43-167). */
+typedef struct sylph_config {
+  int resnet_depth;        /* MODEL.RESNETS.DEPTH: 50 | 101 | 152 */
+  int stride_in_1x1;       /* MODEL.RESNETS.STRIDE_IN_1X1 */
+  int num_cls_convs;       /* MODEL.FCOS.NUM_CLS_CONVS */
+  int num_box_convs;       /* MODEL.FCOS.NUM_BOX_CONVS */
+  int nlevels;             /* len(MODEL.FCOS.FPN_STRIDES) == 5 */
+  int strides[8];          /* MODEL.FCOS.FPN_STRIDES */
+  float pixel_mean[3];     /* MODEL.PIXEL_MEAN */
+  float pixel_std[3];      /* MODEL.PIXEL_STD */
+  int size_divisibility;   /* backbone.size_divisibility (32) */
+  int use_scale;           /* MODEL.FCOS.USE_SCALE */
+  int cond_use_bias;       /* MODEL.META_LEARN.CODE_GENERATOR.USE_BIAS (CondConvBasic use_bias) */
+  float pre_nms_thresh;    /* MODEL.FCOS.INFERENCE_TH_TEST */
+  int pre_nms_topk;        /* MODEL.FCOS.PRE_NMS_TOPK_TEST */
+  float nms_thresh;        /* MODEL.FCOS.NMS_TH */
+  int post_nms_topk;       /* MODEL.FCOS.POST_NMS_TOPK_TEST */
+  int thresh_with_ctr;     /* MODEL.FCOS.THRESH_WITH_CTR */
+  int quality_mode;        /* MODEL.FCOS.BOX_QUALITY: 0 ["ctrness"], 1 ["iou"], 2 ["ctrness","iou"] */
+  int cg_tower_layers;     /* len(CODE_GENERATOR.TOWER_LAYERS) (each ["GN","ReLU"]) */
+  int cg_has_bias;         /* len(CODE_GENERATOR.BIAS_LAYER) != 0 */
+  int cg_bias_l2_norm;     /* CODE_GENERATOR.BIAS_L2_NORM */
+  int cg_post_norm;        /* CODE_GENERATOR.POST_NORM == "GN" */
+  int cg_conv_l2_norm;     /* CODE_GENERATOR.CONV_L2_NORM */
+  int cg_use_weight_scale; /* CODE_GENERATOR.USE_WEIGHT_SCALE */
+  float prior_prob;        /* MODEL.FCOS.PRIOR_PROB */
+  int cand_cap;            /* per (image, level) candidate capacity of the decode scan (0 = default) */
+} sylph_config;
+
+/* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */
+void sylph_config_default(sylph_config* cfg);
+
+/* Context.  dtype = SYLPH_BF16 (bf16 storage + MFMA, fp32 accumulate) or SYLPH_F32 (parity mode). */
+int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out);
+void sylph_ctx_destroy(sylph_ctx* ctx);
+const char* sylph_last_error(void);
+int sylph_set_stream(sylph_ctx* ctx, void* hip_stream);
+int sylph_set_config(sylph_ctx* ctx, const sylph_config* cfg);
+
+/* Weights: replaces DetectionCheckpointer(model).load (sylph/predictor.py:87-88).  name is the
+ * reference state-dict key, data is host fp32 in the reference's tensor layout.
+ * sylph_finalize_weights packs them for the kernels (K-major bf16/fp32, folded FrozenBN). */
+int sylph_load_weight(sylph_ctx* ctx, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int sylph_finalize_weights(sylph_ctx* ctx);
+
+/* MetaProposalNetwork.convert_batched_inputs_to_image_list
+ * (sylph/modeling/meta_arch/meta_one_stage_detector.py:174-178): B device images, each (3,h,w) fp32
+ * BGR 0-255 -> normalised, zero padded to a common size divisible by size_divisibility.
+ * Host arrays: images_dev[B], heights[B], widths[B].  Returns the padded size. */
+int sylph_preprocess(sylph_ctx* ctx, int B, const float* const* images_dev, const int* heights, const int* widths,
+                     int* padded_h, int* padded_w);
+
+/* self.backbone(images.tensor) (meta_one_stage_detector.py:181,273): ResNet-FPN on the current batch. */
+int sylph_backbone_fpn(sylph_ctx* ctx);
+
+/* Boundary/test entry: make (B, padded H, W) the current batch and load its FPN pyramid from
+ * nlevels device tensors (B,256,h_l,w_l) fp32 NCHW.  heights/widths: per-image unpadded sizes. */
+int sylph_import_pyramid(sylph_ctx* ctx, int B, int padded_h, int padded_w, const int* heights, const int* widths,
+                         const float* const* levels_nchw_dev);
+/* Copy level `level` of the current pyramid to a (B,256,h_l,w_l) fp32 NCHW device tensor. */
+int sylph_export_pyramid(sylph_ctx* ctx, int level, float* out_nchw_dev);
+
+/* MetaFCOSHead.forward with support_set_per_class_code (sylph/modeling/meta_fcos/fcos.py:582-667;
+ * CondConvBasic sylph/modeling/meta_fcos/head_utils.py:60-81).  cls_conv_dev: (N,256) fp32,
+ * cls_bias_dev: (N) fp32 or NULL.  Results stay in the context (see sylph_export_head). */
+int sylph_fcos_head(sylph_ctx* ctx, const float* cls_conv_dev, const float* cls_bias_dev, int N);
+/* logits (B,N,h,w), reg (B,4,h,w) = relu(scale_l*bbox_pred), ctr (B,1,h,w), iou (B,1,h,w); NULL skips. */
+int sylph_export_head(sylph_ctx* ctx, int level, float* logits_nchw_dev, float* reg_nchw_dev, float* ctr_nchw_dev,
+                      float* iou_nchw_dev);
+
+/* FCOSOutputs.predict_proposals + select_over_all_levels + detector_postprocess
+ * (sylph/modeling/meta_fcos/fcos_outputs.py:743-812,904-1028; meta_one_stage_detector.py:288-296).
+ * out_heights/out_widths (host, may be NULL = image size): the "height"/"width" of each input dict.
+ * Device outputs, row-major [B][max_out][...]; counts_dev[B]; status_dev[1] (bit0 candidate
+ * overflow, bit1 output truncated).  cand_dev: (level, location, class) ordinal of each detection. */
+int sylph_decode_nms(sylph_ctx* ctx, const int* out_heights, const int* out_widths, int max_out, float* boxes_dev,
+                     float* scores_dev, int* classes_dev, int* levels_dev, float* locations_dev, int* cand_dev,
+                     int* counts_dev, int* status_dev);
+
+/* CodeGenerator.forward / CodeGeneratorHead.forward_roi_align, eval branch
+ * (sylph/modeling/code_generator/code_generator.py:924-1002): the current batch is the S support
+ * images of ONE class; boxes_dev (S,4) fp32 XYXY (one gt box per image).  code_out_dev: 257 fp32 =
+ * un-normalised cls_conv[256] ++ cls_bias[1]. */
+int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
+
+/* CodeGeneratorHead.forward_normalize_code (code_generator.py:832-897): codes_dev (n,257) in place. */
+int sylph_normalize_codes(sylph_ctx* ctx, float* codes_dev, int n);
+
+/* Primitive entries used by the kernel parity tests (F.conv2d / F.group_norm equivalents).
+ * x: (B,C,H,W) fp32 NCHW device; w_host: (Cout,Cin,KH,KW) fp32 host; scale/shift host (Cout) or NULL;
+ * residual: (B,Cout,Ho,Wo) device or NULL; y: (B,Cout,Ho,Wo) fp32 device. */
+int sylph_conv2d(sylph_ctx* ctx, const float* x_nchw_dev, int B, int C, int H, int W, const float* w_host, int Cout,
+                 int KH, int KW, int stride, int pad, const float* scale_host, const float* shift_host, int relu,
+                 const float* residual_nchw_dev, float* y_nchw_dev);
+int sylph_group_norm(sylph_ctx* ctx, const float* x_nchw_dev, int B, int H, int W, const float* gamma_host,
+                     const float* beta_host, int relu, float* y_nchw_dev);
+
+/* Bytes of device memory currently held by the context (weights + workspace). */
+int64_t sylph_device_bytes(sylph_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYLPH_HIP_H */

@@ -1,0 +1,173 @@
+// Support-set path of the Sylph hypernetwork ("code generator") on gfx950: FPN level assignment +
+// ROIAlignV2 gather, per-class code aggregation over positions and shots (wavefront/block
+// reductions), and class-code normalisation (GroupNorm(32) on a 256-vector, L2 normalise, scale).
+// Compiled with -ffp-contract=off so sampling coordinates round like the fp32 reference.
+//
+// Reference arithmetic followed (paths relative to /root/reference):
+//   sylph/modeling/code_generator/code_generator.py:341-348,928-930  ROIPooler(7, scales, 0, "ROIAlignV2")
+//     (detectron2 assign_boxes_to_levels + torchvision roi_align, aligned=True, adaptive sampling)
+//   sylph/modeling/code_generator/code_generator.py:954-967          conv/bias features, BIAS_L2_NORM
+//   sylph/modeling/code_generator/utils.py:51-67                     GlobalAdaptiveAvgPool2d
+//   sylph/modeling/code_generator/code_generator.py:778-829          compute_code (uniform 1/S)
+//   sylph/modeling/code_generator/code_generator.py:832-875          normalize_code / process_bias
+#include "common.h"
+#include "kernels.h"
+
+namespace sylph {
+
+template <typename T>
+__device__ __forceinline__ float bilinear_at(const T* __restrict__ feat, int ld, int row0, int H, int W, float y,
+                                             float x, int c) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - (float)y_low, lx = x - (float)x_low;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  const float v1 = Cvt<T>::to_f(feat[(size_t)(row0 + y_low * W + x_low) * ld + c]);
+  const float v2 = Cvt<T>::to_f(feat[(size_t)(row0 + y_low * W + x_high) * ld + c]);
+  const float v3 = Cvt<T>::to_f(feat[(size_t)(row0 + y_high * W + x_low) * ld + c]);
+  const float v4 = Cvt<T>::to_f(feat[(size_t)(row0 + y_high * W + x_high) * ld + c]);
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+// grid (out*out, S), block C threads (channel per thread: channel-contiguous gathers)
+template <typename T>
+__global__ void roi_align_kernel(const T* __restrict__ feats, int ld, const LevelDesc* __restrict__ lv, int nlevels,
+                                 const float* __restrict__ boxes, int out_size, int C, T* __restrict__ out) {
+  const int s = blockIdx.y, bin = blockIdx.x;
+  const int ph = bin / out_size, pw = bin - ph * out_size;
+  const float bx1 = boxes[s * 4 + 0], by1 = boxes[s * 4 + 1], bx2 = boxes[s * 4 + 2], by2 = boxes[s * 4 + 3];
+  int lvl = 0;
+  if (nlevels > 1) {
+    const float area = (bx2 - bx1) * (by2 - by1);
+    const float sz = sqrtf(area);
+    float l = floorf(4.0f + log2f(sz / 224.0f + 1e-8f));
+    const float min_level = -log2f(lv[0].scale);  // 3 for stride 8
+    l = fminf(fmaxf(l, min_level), min_level + (float)(nlevels - 1));
+    lvl = (int)(l - min_level);
+  }
+  const LevelDesc d = lv[s * nlevels + lvl];
+  const float x1 = bx1 * d.scale - 0.5f, y1 = by1 * d.scale - 0.5f;
+  const float x2 = bx2 * d.scale - 0.5f, y2 = by2 * d.scale - 0.5f;
+  const float rw = x2 - x1, rh = y2 - y1;
+  const float bw = rw / (float)out_size, bh = rh / (float)out_size;
+  const int gh = (int)ceilf(bh), gw = (int)ceilf(bw);
+  const float count = (float)max(gh * gw, 1);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      const float yy = y1 + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float xx = x1 + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+        acc += bilinear_at<T>(feats, ld, d.row0, d.H, d.W, yy, xx, c);
+      }
+    }
+    out[((size_t)s * out_size * out_size + bin) * C + c] = Cvt<T>::from_f(acc / count);
+  }
+}
+
+int launch_roi_align(DType dt, const void* feats, int ld, const LevelDesc* lv_dev, int nlevels,
+                     const float* boxes_dev, int S, int out_size, void* out, hipStream_t s) {
+  const int C = 256;
+  dim3 grid(out_size * out_size, S), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(roi_align_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)feats, ld, lv_dev, nlevels,
+                       boxes_dev, out_size, C, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(roi_align_kernel<float>, grid, block, 0, s, (const float*)feats, ld, lv_dev, nlevels, boxes_dev,
+                       out_size, C, (float*)out);
+  return (int)hipGetLastError();
+}
+
+// conv_out [S*npos][conv_ld] fp32, bias_out [S*npos][bias_ld] fp32 (channel 0) -> code_out[C+1]
+__global__ __launch_bounds__(256) void codegen_tail_kernel(const float* __restrict__ conv_out, int conv_ld,
+                                                           const float* __restrict__ bias_out, int bias_ld, int S,
+                                                           int npos, int C, int bias_l2_norm, int has_bias,
+                                                           float* __restrict__ code_out) {
+  const float wshot = 1.0f / (float)S;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float code = 0.f;
+    for (int s = 0; s < S; ++s) {
+      float sum = 0.f;
+      for (int p = 0; p < npos; ++p) sum += conv_out[((size_t)s * npos + p) * conv_ld + c];
+      code += wshot * (sum / (float)npos);
+    }
+    code_out[c] = code;
+  }
+  if (threadIdx.x < 64) {  // one wave: bias head
+    const int lane = threadIdx.x;
+    float bias = 0.f;
+    if (has_bias) {
+      for (int s = 0; s < S; ++s) {
+        const float v = lane < npos ? bias_out[((size_t)s * npos + lane) * bias_ld] : 0.f;  // npos <= 64
+        float nrm = 1.f;
+        if (bias_l2_norm) {
+          float sq = v * v;
+          for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+          nrm = fmaxf(sqrtf(sq), 1e-12f);
+        }
+        float t = v / nrm;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        bias += wshot * (t / (float)npos);
+      }
+    }
+    if (lane == 0) code_out[C] = bias;
+  }
+}
+
+int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int S, int npos, int C,
+                        int bias_l2_norm, int has_bias, float* code_out, hipStream_t s) {
+  if (npos > 64) return -1;
+  hipLaunchKernelGGL(codegen_tail_kernel, dim3(1), dim3(256), 0, s, conv_out, conv_ld, bias_out, bias_ld, S, npos, C,
+                     bias_l2_norm, has_bias, code_out);
+  return (int)hipGetLastError();
+}
+
+// codes [ncodes][C+1] in place; one block of 256 threads per code, C == 256 (8 channels / group)
+__global__ __launch_bounds__(256) void normalize_codes_kernel(float* __restrict__ codes, int C,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int post_norm,
+                                                              int l2_norm, float conv_scale, float bias_scale,
+                                                              float bias_prior) {
+  float* code = codes + (size_t)blockIdx.x * (C + 1);
+  const int c = threadIdx.x;
+  float v = c < C ? code[c] : 0.f;
+  if (post_norm && (C % 32 == 0)) {
+    // groups of C/32 = 8 consecutive channels -> 8 consecutive lanes
+    float s = v;
+    for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / 8.f;
+    const float d = v - mean;
+    float q = d * d;
+    for (int o = 4; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / 8.f + 1e-5f);
+    v = d * rstd * gamma[c] + beta[c];
+  }
+  if (l2_norm) {
+    __shared__ float part[4];
+    float sq = v * v;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((c & 63) == 0) part[c >> 6] = sq;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(part[0] + part[1] + part[2] + part[3]), 1e-12f);
+    v = v / nrm;
+  }
+  v = v * conv_scale;
+  if (c < C) code[c] = v;
+  if (c == 0) code[C] = code[C] * bias_scale + bias_prior;
+}
+
+int launch_normalize_codes(float* codes, int ncodes, int C, const float* gn_gamma, const float* gn_beta,
+                           int post_norm, int l2_norm, float conv_scale, float bias_scale, float bias_prior,
+                           hipStream_t s) {
+  if (C != 256) return -1;
+  hipLaunchKernelGGL(normalize_codes_kernel, dim3(ncodes), dim3(256), 0, s, codes, C, gn_gamma, gn_beta, post_norm,
+                     l2_norm, conv_scale, bias_scale, bias_prior);
+  return (int)hipGetLastError();
+}
+
+}  // namespace sylph

@@ -1,0 +1,89 @@
+// Shared device/host declarations for the Sylph MI355X (gfx950) inference library.
+// Activations live in HBM as position-major ("NHWC") rows: one row = one spatial position,
+// C contiguous channels, either bf16 (throughput mode) or fp32 (parity mode).  A feature map is a
+// list of SEGMENTS (one per image, or one per image x FPN level); segment s owns rows
+// [row0, row0 + H*W).  Every kernel takes its geometry from a small device-resident table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sylph {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+
+// One segment of a convolution problem.  All *_row0 are row indices into the respective buffers.
+struct SegDesc {
+  int in_row0, in_H, in_W;
+  int out_row0, out_H, out_W;
+  int res_row0, res_H, res_W;  // residual source geometry (res_mode 2: half resolution)
+  float mul;                   // per-segment multiplier (FCOS Scale_l), applied to channels < mul_nch
+  int pad0, pad1;
+};
+
+struct ConvArgs {
+  const void* in;
+  const void* wt;     // packed [Cout_pad][KH][KW][Cin] in the compute dtype
+  void* out;
+  const void* res;    // optional residual (compute dtype), row stride res_ld
+  const float* scale; // per-output-channel epilogue scale (nullptr -> 1)
+  const float* shift; // per-output-channel epilogue shift (nullptr -> 0)
+  const SegDesc* segs;
+  const int2* tiles;  // tiles[t] = {segment, first row of the tile inside the segment}
+  int n_mtiles, n_ntiles;
+  int Cin, Cout, KH, KW, stride, pad;
+  int in_ld, out_ld, res_ld;  // row strides in elements
+  int relu_nch;               // ReLU on output channels < relu_nch
+  int mul_nch;                // seg.mul on output channels < mul_nch
+  int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
+  int in_relu;                // apply ReLU to the input while staging (P7 = conv(relu(P6)))
+};
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  static __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }
+};
+
+__device__ __forceinline__ float bf16_bits_to_f(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+
+// load 8 consecutive elements of T as floats (16-byte aligned for bf16, 32-byte span for f32)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// ---- launcher prototypes (one per translation unit) -----------------------------------------
+// conv_igemm.hip
+int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);
+void conv_pick_tile(int rows_total, int cout, int* BM, int* BN);
+
+}  // namespace sylph

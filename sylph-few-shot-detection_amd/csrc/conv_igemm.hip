@@ -1,0 +1,271 @@
+// Implicit-GEMM convolution on MFMA for gfx950.
+//
+//   out[pos][n] = epi( sum_{kh,kw,c} in[pos*stride + (kh,kw) - pad][c] * wt[n][kh][kw][c] )
+//
+// GEMM view: M = output positions (rows of the position-major activation buffer), N = Cout,
+// K = KH*KW*Cin walked tap-major in 128-byte slices (64 bf16 / 32 fp32), so a K-slice never
+// straddles a tap and the A operand of a slice is one 128-byte span of one input row: the im2col
+// gather is a per-row address + a 9-bit validity mask computed once per tile.
+// Both operands are K-contiguous ([pos][C] activations, [n][kh][kw][c] weights), which is the
+// layout the 32x32 MFMA fragments want (8 bf16 / 1 fp32 along K per lane).
+//
+// Block = 256 threads = 4 wave64 arranged WGM x WGN; wave tile (BM/WGM) x (BN/WGN) made of
+// 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, or the exact-fp32 v_mfma_f32_32x32x2_f32 in
+// parity mode).  Global->register->LDS staging, LDS double-buffered, one barrier per K-slice.
+// LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 so the
+// ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-byte slots.
+// Epilogue (fused): per-channel scale/shift (FrozenBN or bias), residual add (optionally through
+// a nearest 2x upsample: the FPN top-down path), per-segment Scale_l, ReLU, store bf16/fp32.
+// Reference ops replaced: every F.conv2d / nn.Conv2d on the path: ResNet bottleneck
+// convs + FrozenBN (detectron2), FPN lateral/output/P6/P7, FCOS towers (fcos.py:72-122),
+// bbox_pred/ctrness (fcos.py:656-664), CondConvBasic (head_utils.py:60-81), code-generator
+// convs (code_generator.py:509-688).
+#include "common.h"
+
+namespace sylph {
+
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16_t> {
+  static constexpr int KSTEPS = 4;  // 64 bf16 per slice / 16 per MFMA
+  typedef bf16x8 frag_t;
+  static __device__ __forceinline__ frag_t load(const char* tile, int row, int ks, int lane) {
+    const int chunk = ks * 2 + (lane >> 5);
+    const int sw = chunk ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const frag_t*>(tile + row * 128 + sw * 16);
+  }
+  static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <> struct Mma<float> {
+  static constexpr int KSTEPS = 16;  // 32 fp32 per slice / 2 per MFMA
+  typedef float frag_t;
+  static __device__ __forceinline__ frag_t load(const char* tile, int row, int ks, int lane) {
+    const int k = ks * 2 + (lane >> 5);
+    const int sw = (k >> 2) ^ ((row >> 1) & 7);
+    return *reinterpret_cast<const float*>(tile + row * 128 + sw * 16 + (k & 3) * 4);
+  }
+  static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ uint4 relu_pack(uint4 v, float) {
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = f[i] > 0.f ? f[i] : 0.f;
+  return v;
+}
+__device__ __forceinline__ uint4 relu_pack(uint4 v, bf16_t) {
+  uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t neg = (u[i] >> 15) & 0x00010001u;  // sign bits of the two halves
+    u[i] &= ~(neg * 0xffffu);
+  }
+  return v;
+}
+
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
+  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad tile");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sA = smem;                   // [2][BM][128]
+  char* const sB = smem + 2 * BM * 128;    // [2][BN][128]
+
+  // XCD-aware block -> tile map: XCD x owns a contiguous chunk of M-tiles; inside it the N index
+  // is innermost so consecutive blocks of one XCD share the A tile through that XCD's L2.
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q = L >> 3;
+  const int chunk = (a.n_mtiles + 7) >> 3;
+  const int m_local = q / a.n_ntiles;
+  const int nt = q - m_local * a.n_ntiles;
+  const int mt = xcd * chunk + m_local;
+  if (m_local >= chunk || mt >= a.n_mtiles) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int c16 = tid & 7, r0 = tid >> 3;
+
+  const int2 tile = a.tiles[mt];
+  const SegDesc sd = a.segs[tile.x];
+  const int seg_rows = sd.out_H * sd.out_W;
+
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+  const int Cin = a.Cin, KW = a.KW, ntaps = a.KH * a.KW;
+  const int cpt = Cin / BK;            // K-slices per tap
+  const int nk = ntaps * cpt;
+  const int Ktot = ntaps * Cin;
+
+  int abase[AR];
+  uint32_t amask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int pos = tile.y + r0 + 32 * i;
+    const bool rv = pos < seg_rows;
+    const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+    abase[i] = (sd.in_row0 + iy0 * sd.in_W + ix0) * a.in_ld + c16 * EPC;
+    uint32_t m = 0;
+    for (int t = 0; t < ntaps; ++t) {
+      const int kh = t / KW, kw = t - kh * KW;
+      const bool ok = rv && (unsigned)(iy0 + kh) < (unsigned)sd.in_H && (unsigned)(ix0 + kw) < (unsigned)sd.in_W;
+      m |= (ok ? 1u : 0u) << t;
+    }
+    amask[i] = m;
+  }
+  size_t bbase[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + 32 * j) * Ktot + c16 * EPC;
+
+  uint4 ra[AR], rb[BR];
+  int tap = 0, cc = 0, kh = 0, kw = 0;  // state of the NEXT slice to fetch
+  auto fetch = [&]() {
+    const int aoff = (kh * sd.in_W + kw) * a.in_ld + cc * BK;
+    const int boff = tap * Cin + cc * BK;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((amask[i] >> tap) & 1u) v = *reinterpret_cast<const uint4*>(in + (abase[i] + aoff));
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const uint4*>(wt + (bbase[j] + boff));
+    if (++cc == cpt) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
+  };
+  auto stash = [&](int buf) {
+    char* dA = sA + buf * BM * 128;
+    char* dB = sB + buf * BN * 128;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int row = r0 + 32 * i;
+      uint4 v = ra[i];
+      if (a.in_relu) v = relu_pack(v, T());
+      *reinterpret_cast<uint4*>(dA + row * 128 + ((c16 ^ ((row >> 1) & 7)) * 16)) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int row = r0 + 32 * j;
+      *reinterpret_cast<uint4*>(dB + row * 128 + ((c16 ^ ((row >> 1) & 7)) * 16)) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch();
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) fetch();
+    const char* tA = sA + buf * BM * 128;
+    const char* tB = sB + buf * BN * 128;
+#pragma unroll
+    for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
+      typename Mma<T>::frag_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = Mma<T>::load(tA, wm * WTM + i * 32 + (lane & 31), ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = Mma<T>::load(tB, wn * WTN + j * 32 + (lane & 31), ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- fused epilogue -------------------------------------------------------------------------
+  OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nt * BN + wn * WTN + j * 32 + (lane & 31);
+    const bool nv = n < a.Cout;
+    const float sc = (nv && a.scale) ? a.scale[n] : 1.f;
+    const float sh = (nv && a.shift) ? a.shift[n] : 0.f;
+    const float mul = (n < a.mul_nch) ? sd.mul : 1.f;
+    const bool relu = n < a.relu_nch;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int pos = tile.y + row;
+        if (nv && pos < seg_rows) {
+          float v = acc[i][j][r] * sc + sh;
+          if (a.res_mode == 1) {
+            v += Cvt<T>::to_f(res[(size_t)(sd.res_row0 + pos) * a.res_ld + n]);
+          } else if (a.res_mode == 2) {
+            const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+            const int rp = (oy >> 1) * sd.res_W + (ox >> 1);
+            v += Cvt<T>::to_f(res[(size_t)(sd.res_row0 + rp) * a.res_ld + n]);
+          }
+          v *= mul;
+          if (relu) v = v > 0.f ? v : 0.f;
+          out[(size_t)(sd.out_row0 + pos) * a.out_ld + n] = Cvt<OutT>::from_f(v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+  const int chunk = (a.n_mtiles + 7) / 8;
+  const int grid = 8 * chunk * a.n_ntiles;
+  const size_t lds = 2 * (BM + BN) * 128;
+  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN>;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+template <typename T, typename OutT>
+static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
+  if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
+  if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2>(a, s);
+  if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1>(a, s);
+  if (BM == 64 && BN == 128) return launch_cfg<T, OutT, 64, 128, 2, 2>(a, s);
+  if (BM == 64 && BN == 64) return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
+  return -1;
+}
+
+// Tile choice: widest N tile the layer fills; drop to BM=64 when the grid would not fill 256 CUs.
+void conv_pick_tile(int rows_total, int cout, int* BM, int* BN) {
+  int bn = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
+  int bm = 128;
+  if (bn != 32) {
+    const long blocks128 = (long)((rows_total + 127) / 128) * ((cout + bn - 1) / bn);
+    if (blocks128 < 512) bm = 64;
+  }
+  *BM = bm;
+  *BN = bn;
+}
+
+int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s) {
+  if (a.KH * a.KW > 32) return -3;
+  const int bk = dt == DT_BF16 ? 64 : 32;
+  if (a.Cin % bk != 0) return -4;
+  if (dt == DT_BF16) {
+    return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);
+  }
+  return launch_t<float, float>(a, BM, BN, s);
+}
+
+}  // namespace sylph

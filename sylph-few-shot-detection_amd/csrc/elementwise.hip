@@ -1,0 +1,377 @@
+// HBM-bound kernels of the Sylph inference path (gfx950): pixel normalisation + padding, ResNet stem
+// (7x7 s2 conv + FrozenBN + ReLU, direct fp32 FMA with wave-uniform weights), 3x3 s2 max-pool,
+// GroupNorm(32 groups x 8 channels) statistics / apply(+ReLU), layout import/export.
+// All activation traffic is 16 bytes per lane (8 bf16 or 2x float4), rows are channel-contiguous.
+//
+// Reference ops replaced (paths relative to /root/reference):
+//   preprocess  : sylph/modeling/meta_arch/meta_one_stage_detector.py:174-178 (+ d2 ImageList.from_tensors)
+//   stem/maxpool: detectron2 BasicStem, called via meta_one_stage_detector.py:181,273
+//   GroupNorm   : nn.GroupNorm(32, C) in sylph/modeling/meta_fcos/fcos.py:97-98 and
+//                 sylph/modeling/code_generator/code_generator.py:648-688 (build_fpn_norm "GN")
+#include "common.h"
+#include "kernels.h"
+
+namespace sylph {
+
+// ------------------------------------------------------------------------------------------------
+// preprocess: list of (3,h,w) fp32 planes -> [B][H][W][4] (4th channel = 0), zero padded.
+template <typename T>
+__global__ void preprocess_kernel(const ImageDesc* imgs, T* out, int H, int W, float m0, float m1, float m2,
+                                  float is0, float is1, float is2) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= W) return;
+  const ImageDesc d = imgs[b];
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+  if (y < d.h && x < d.w) {
+    const size_t plane = (size_t)d.h * d.w;
+    const float* p = d.ptr + (size_t)y * d.w + x;
+    v0 = (p[0] - m0) * is0;
+    v1 = (p[plane] - m1) * is1;
+    v2 = (p[2 * plane] - m2) * is2;
+  }
+  T* o = out + (((size_t)b * H + y) * W + x) * 4;
+  o[0] = Cvt<T>::from_f(v0); o[1] = Cvt<T>::from_f(v1); o[2] = Cvt<T>::from_f(v2); o[3] = Cvt<T>::from_f(0.f);
+}
+
+int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int H, int W, const float* mean,
+                      const float* stdv, hipStream_t s) {
+  dim3 grid((W + 255) / 256, H, B), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(preprocess_kernel<bf16_t>, grid, block, 0, s, imgs_dev, (bf16_t*)out, H, W, mean[0], mean[1],
+                       mean[2], 1.f / stdv[0], 1.f / stdv[1], 1.f / stdv[2]);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<float>, grid, block, 0, s, imgs_dev, (float*)out, H, W, mean[0], mean[1],
+                       mean[2], 1.f / stdv[0], 1.f / stdv[1], 1.f / stdv[2]);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem: in [B][H][W][4], w fp32 [7][7][3][64] (wave-uniform index -> scalar loads), out [B][Ho][Wo][64]
+template <typename T> __device__ __forceinline__ void load_px3(const T* p, float& a, float& b, float& c);
+template <> __device__ __forceinline__ void load_px3<float>(const float* p, float& a, float& b, float& c) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  a = v.x; b = v.y; c = v.z;
+}
+template <> __device__ __forceinline__ void load_px3<bf16_t>(const bf16_t* p, float& a, float& b, float& c) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  a = __uint_as_float(v.x << 16); b = __uint_as_float(v.x & 0xffff0000u); c = __uint_as_float(v.y << 16);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, T* __restrict__ out, int H,
+                                                        int W, int Ho, int Wo) {
+  const int b = blockIdx.z, oy = blockIdx.y;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = ox < Wo;
+  float acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  const int iy0 = oy * 2 - 3, ix0 = ox * 2 - 3;
+  for (int kh = 0; kh < 7; ++kh) {
+    const int iy = iy0 + kh;
+    if ((unsigned)iy >= (unsigned)H) continue;  // uniform per block
+    const T* rowp = in + ((size_t)b * H + iy) * W * 4;
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+      const int ix = ix0 + kw;
+      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+      if (active && (unsigned)ix < (unsigned)W) load_px3<T>(rowp + (size_t)ix * 4, p0, p1, p2);
+      const float* wp = w + (kh * 7 + kw) * 3 * 64;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) {
+        acc[c] = fmaf(p0, wp[c], acc[c]);
+        acc[c] = fmaf(p1, wp[64 + c], acc[c]);
+        acc[c] = fmaf(p2, wp[128 + c], acc[c]);
+      }
+    }
+  }
+  if (!active) return;
+  T* o = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
+#pragma unroll
+  for (int c0 = 0; c0 < 64; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float t = acc[c0 + j] * scale[c0 + j] + shift[c0 + j];
+      v[j] = t > 0.f ? t : 0.f;
+    }
+    store8<T>(o + c0, v);
+  }
+}
+
+int launch_stem(DType dt, const void* in, const float* w, const float* scale, const float* shift, void* out, int B,
+                int H, int W, int Ho, int Wo, hipStream_t s) {
+  dim3 grid((Wo + 255) / 256, Ho, B), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(stem_conv_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)in, w, scale, shift, (bf16_t*)out,
+                       H, W, Ho, Wo);
+  else
+    hipLaunchKernelGGL(stem_conv_kernel<float>, grid, block, 0, s, (const float*)in, w, scale, shift, (float*)out, H,
+                       W, Ho, Wo);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// max-pool 3x3 stride 2 pad 1 over [B][H][W][C]; one thread = 8 channels of one output position.
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int Ho,
+                               int Wo) {
+  const int cg = C / 8;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * Ho * Wo * cg;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % cg);
+  size_t p = idx / cg;
+  const int ox = (int)(p % Wo); p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int b = (int)(p / Ho);
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 - 1 + dy;
+    if ((unsigned)iy >= (unsigned)H) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 - 1 + dx;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      float v[8];
+      load8<T>(in + (((size_t)b * H + iy) * W + ix) * C + c8 * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+    }
+  }
+  store8<T>(out + (((size_t)b * Ho + oy) * Wo + ox) * C + c8 * 8, m);
+}
+
+int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s) {
+  const size_t total = (size_t)B * Ho * Wo * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)in, (bf16_t*)out, B, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<float>, grid, block, 0, s, (const float*)in, (float*)out, B, H, W, C, Ho, Wo);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(32, 256): 8 channels per group == one 16-byte (bf16) lane load.
+// Pass 1: block (chunk, seg): 256 threads = 32 groups x 8 row-lanes; shifted sums per thread, Chan
+// combine across the 8 row-lanes in LDS -> partial (n, mean, M2) per (seg, chunk, group).
+// Pass 2: one thread per (seg, group) folds the chunks in a fixed order (deterministic) -> mean, rstd.
+// Pass 3: y = relu((x - mean) * rstd * gamma + beta), in place.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, const RowSeg* segs, int ld,
+                                                       int rows_per_chunk, int max_chunks,
+                                                       float* __restrict__ partial) {
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const RowSeg sg = segs[seg];
+  const int r_begin = chunk * rows_per_chunk;
+  if (r_begin >= sg.nrows) return;
+  const int r_end = min(sg.nrows, r_begin + rows_per_chunk);
+  const int g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  float n = 0.f, s1 = 0.f, s2 = 0.f, K = 0.f;
+  bool first = true;
+  for (int r = r_begin + rl; r < r_end; r += 8) {
+    float v[8];
+    load8<T>(x + (size_t)(sg.row0 + r) * ld + g * 8, v);
+    if (first) { K = v[0]; first = false; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = v[j] - K;
+      s1 += d;
+      s2 = fmaf(d, d, s2);
+    }
+    n += 8.f;
+  }
+  float mean = 0.f, m2 = 0.f;
+  if (n > 0.f) {
+    const float md = s1 / n;
+    mean = K + md;
+    m2 = fmaxf(s2 - s1 * md, 0.f);
+  }
+  __shared__ float sh[3][8][32];
+  sh[0][rl][g] = n; sh[1][rl][g] = mean; sh[2][rl][g] = m2;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float N = 0.f, M = 0.f, Q = 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const float nb = sh[0][i][g];
+      if (nb > 0.f) {
+        const float mb = sh[1][i][g], qb = sh[2][i][g];
+        const float nn = N + nb, delta = mb - M;
+        M += delta * (nb / nn);
+        Q += qb + delta * delta * (N * nb / nn);
+        N = nn;
+      }
+    }
+    float* p = partial + (((size_t)seg * max_chunks + chunk) * 32 + g) * 3;
+    p[0] = N; p[1] = M; p[2] = Q;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, const RowSeg* segs, int nseg,
+                                   int rows_per_chunk, int max_chunks, float eps, float2* __restrict__ stats) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nseg * 32) return;
+  const int seg = idx >> 5, g = idx & 31;
+  const int nchunks = (segs[seg].nrows + rows_per_chunk - 1) / rows_per_chunk;
+  double N = 0.0, M = 0.0, Q = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* p = partial + (((size_t)seg * max_chunks + c) * 32 + g) * 3;
+    const double nb = p[0], mb = p[1], qb = p[2];
+    if (nb > 0.0) {
+      const double nn = N + nb, delta = mb - M;
+      M += delta * (nb / nn);
+      Q += qb + delta * delta * (N * nb / nn);
+      N = nn;
+    }
+  }
+  const double var = N > 0.0 ? Q / N : 0.0;
+  stats[idx] = make_float2((float)M, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const RowSeg* segs, int ld,
+                                                       int rows_per_chunk, const float2* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu) {
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const RowSeg sg = segs[seg];
+  const int r_begin = chunk * rows_per_chunk;
+  if (r_begin >= sg.nrows) return;
+  const int r_end = min(sg.nrows, r_begin + rows_per_chunk);
+  const int g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const float2 st = stats[seg * 32 + g];
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = st.y * gamma[g * 8 + j];
+    b[j] = beta[g * 8 + j] - st.x * a[j];
+  }
+  for (int r = r_begin + rl; r < r_end; r += 8) {
+    T* p = x + (size_t)(sg.row0 + r) * ld + g * 8;
+    float v[8];
+    load8<T>(p, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = fmaf(v[j], a[j], b[j]);
+      if (relu) t = t > 0.f ? t : 0.f;
+      v[j] = t;
+    }
+    store8<T>(p, v);
+  }
+}
+
+int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
+                     const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s) {
+  const int rpc = GN_ROWS_PER_CHUNK;
+  const int max_chunks = (max_rows + rpc - 1) / rpc;
+  dim3 grid(max_chunks, nseg), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, segs_dev, ld, rpc, max_chunks,
+                       partial);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, block, 0, s, (const float*)x, segs_dev, ld, rpc, max_chunks,
+                       partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((nseg * 32 + 255) / 256), dim3(256), 0, s, partial, segs_dev, nseg, rpc,
+                     max_chunks, eps, stats);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, rpc, stats, gamma, beta,
+                       relu);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, rpc, stats, gamma, beta,
+                       relu);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion (API boundary + tests): NCHW fp32 <-> position-major rows
+template <typename T>
+__global__ void import_nchw_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int HW, int row0,
+                                   int ld) {
+  // one block = 64 positions x 64 channels through LDS (transpose)
+  __shared__ float t[64][65];
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows at a time
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, p = p0 + tx;
+    t[i][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int p = p0 + i, c = c0 + tx;
+    if (p < HW && c < C) dst[(size_t)(row0 + p) * ld + c] = Cvt<T>::from_f(t[tx][i]);
+  }
+}
+
+template <typename T>
+__global__ void export_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int HW, int row0,
+                                   int ld) {
+  __shared__ float t[64][65];
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int p = p0 + i, c = c0 + tx;
+    t[i][tx] = (p < HW && c < C) ? Cvt<T>::to_f(src[(size_t)(row0 + p) * ld + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, p = p0 + tx;
+    if (c < C && p < HW) dst[(size_t)c * HW + p] = t[tx][i];
+  }
+}
+
+int launch_import_nchw(DType dt, const float* src, void* dst, int C, int HW, int row0, int ld, hipStream_t s) {
+  dim3 grid((HW + 63) / 64, (C + 63) / 64), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(import_nchw_kernel<bf16_t>, grid, block, 0, s, src, (bf16_t*)dst, C, HW, row0, ld);
+  else
+    hipLaunchKernelGGL(import_nchw_kernel<float>, grid, block, 0, s, src, (float*)dst, C, HW, row0, ld);
+  return (int)hipGetLastError();
+}
+
+int launch_export_nchw(DType dt, const void* src, float* dst, int C, int HW, int row0, int ld, hipStream_t s) {
+  dim3 grid((HW + 63) / 64, (C + 63) / 64), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(export_nchw_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, dst, C, HW, row0, ld);
+  else
+    hipLaunchKernelGGL(export_nchw_kernel<float>, grid, block, 0, s, (const float*)src, dst, C, HW, row0, ld);
+  return (int)hipGetLastError();
+}
+
+// fp32 rows (head outputs) -> NCHW fp32, channel window [ch0, ch0+C)
+__global__ void export_nchw_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, int row0,
+                                       int ld, int ch0) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (p < HW && c < C) dst[(size_t)c * HW + p] = src[(size_t)(row0 + p) * ld + ch0 + c];
+}
+
+int launch_export_nchw_f32(const float* src, float* dst, int C, int HW, int row0, int ld, int ch0, hipStream_t s) {
+  hipLaunchKernelGGL(export_nchw_f32_kernel, dim3((HW + 255) / 256, C), dim3(256), 0, s, src, dst, C, HW, row0, ld,
+                     ch0);
+  return (int)hipGetLastError();
+}
+
+// class codes (N,C) fp32 -> packed weight rows [Npad][C] in the compute dtype (zero padded)
+template <typename T>
+__global__ void pack_codes_kernel(const float* __restrict__ w, int N, int C, int Npad, T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad * C) return;
+  const int n = i / C;
+  out[i] = Cvt<T>::from_f(n < N ? w[i] : 0.f);
+}
+
+int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, hipStream_t s) {
+  dim3 grid((Npad * C + 255) / 256), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(pack_codes_kernel<bf16_t>, grid, block, 0, s, w, N, C, Npad, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(pack_codes_kernel<float>, grid, block, 0, s, w, N, C, Npad, (float*)out);
+  return (int)hipGetLastError();
+}
+
+}  // namespace sylph

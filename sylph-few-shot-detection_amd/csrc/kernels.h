@@ -1,0 +1,88 @@
+// Launcher prototypes and small device-table structs shared by the translation units.
+#pragma once
+#include "common.h"
+
+namespace sylph {
+
+struct ImageDesc { const float* ptr; int h, w; };   // one (3,h,w) fp32 plane-major image on device
+struct RowSeg { int row0, nrows; };                 // a run of rows (one GroupNorm sample)
+
+constexpr int GN_ROWS_PER_CHUNK = 256;
+
+// One (image, FPN level) slab of the head outputs, for decode.
+struct DecodeSeg {
+  int row0;        // first row in logits / pred buffers
+  int nloc;        // H*W
+  int W;           // feature width
+  int stride;      // FPN stride
+  int level;       // FPN level index (0..)
+  int image;       // batch index
+  unsigned loc_base;  // sum_{l'<l} nloc_l'; global candidate ordinal = (loc_base + loc) * N + cls
+  int pad;
+};
+
+struct DecodeCfg {
+  int num_classes;     // N
+  int logits_ld;       // row stride of logits
+  float pre_nms_thresh;
+  int pre_nms_topk;
+  float nms_thresh;
+  int post_nms_topk;
+  int thresh_with_ctr;
+  int quality_mode;    // 0 ctrness, 1 iou, 2 sqrt(iou*ctrness)
+  int cand_cap;        // per-(image,level) candidate capacity
+  int pool_cap;        // per-image sorted pool capacity (power of two, >= levels*topk)
+  int nlevels;
+  int max_out;         // per-image output capacity
+};
+
+struct DecodeBuffers {
+  // scan
+  unsigned* cand_key;   // [nseg][cand_cap]   float bits of cls*quality
+  unsigned* cand_idx;   // [nseg][cand_cap]   loc*N + cls
+  unsigned* cand_count; // [nseg]
+  // pool (per image)
+  unsigned long long* pool_key;  // [B][pool_cap]  (sqrt-score bits << 32) | ~ordinal
+  unsigned* pool_count;          // [B]
+  // sorted candidates
+  float* s_box;      // [B][pool_cap][4]
+  float* s_score;    // [B][pool_cap]
+  int* s_cls;        // [B][pool_cap]
+  int* s_level;      // [B][pool_cap]
+  float* s_loc;      // [B][pool_cap][2]
+  unsigned* s_ord;   // [B][pool_cap]
+  unsigned long long* mask;  // [B][pool_cap][pool_cap/64]
+  int* status;       // [1] bit0: candidate overflow, bit1: output truncated
+};
+
+struct ImageOut { float sx, sy, out_w, out_h; };  // postprocess scale + clip box per image
+
+// elementwise.hip
+int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int H, int W, const float* mean,
+                      const float* stdv, hipStream_t s);
+int launch_stem(DType dt, const void* in, const float* w, const float* scale, const float* shift, void* out, int B,
+                int H, int W, int Ho, int Wo, hipStream_t s);
+int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
+int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
+                     const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s);
+int launch_import_nchw(DType dt, const float* src, void* dst, int C, int HW, int row0, int ld, hipStream_t s);
+int launch_export_nchw(DType dt, const void* src, float* dst, int C, int HW, int row0, int ld, hipStream_t s);
+int launch_export_nchw_f32(const float* src, float* dst, int C, int HW, int row0, int ld, int ch0, hipStream_t s);
+int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, hipStream_t s);
+
+// detect.hip
+int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int max_nloc, int B, int nw_bound,
+                  const float* logits, const float* pred, int pred_ld, const DecodeBuffers& buf,
+                  const ImageOut* img_out_dev, float* out_boxes, float* out_scores, int* out_classes,
+                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, hipStream_t s);
+
+// codegen.hip
+struct LevelDesc { int row0; int H, W; float scale; };  // per (image, level): rows of the feature pyramid
+int launch_roi_align(DType dt, const void* feats, int ld, const LevelDesc* lv_dev, int nlevels, const float* boxes_dev,
+                     int S, int out_size, void* out, hipStream_t s);
+int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int S, int npos, int C,
+                        int bias_l2_norm, int has_bias, float* code_out, hipStream_t s);
+int launch_normalize_codes(float* codes, int ncodes, int C, const float* gn_gamma, const float* gn_beta, int post_norm,
+                           int l2_norm, float conv_scale, float bias_scale, float bias_prior, hipStream_t s);
+
+}  // namespace sylph

@@ -1,0 +1,1046 @@
+// Host side of libsylph_hip.so: context, weight packing, per-batch-shape execution plans (lists of
+// fully resolved kernel launches over context-owned HBM buffers) and the C ABI of include/sylph_hip.h.
+// No torch types, no CPU compute fallback: every stage is a HIP kernel from this directory.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/sylph_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace sylph;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t e_ = (x);                                                                           \
+    if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+#define RET(x)                     \
+  do {                             \
+    int r_ = (x);                  \
+    if (r_ != 0) return r_;        \
+  } while (0)
+#define KCHK(x, what)                                                                              \
+  do {                                                                                             \
+    int r_ = (x);                                                                                  \
+    if (r_ != 0) return fail(std::string(what) + ": launch failed (" + std::to_string(r_) + ")");  \
+  } while (0)
+
+static inline uint16_t f2bf_host(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+typedef std::function<int(hipStream_t)> OpFn;
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct ConvLayer {
+  void* w = nullptr;       // packed [Cout_pad][KH][KW][Cin]
+  float* scale = nullptr;  // device, Cout_pad (may be null)
+  float* shift = nullptr;
+  int Cin = 0, Cout = 0, Cout_pad = 0, KH = 1, KW = 1;
+};
+struct GNLayer {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+};
+
+struct Plan;
+
+struct sylph_ctx {
+  int device = 0;
+  DType dt = DT_BF16;
+  hipStream_t stream = nullptr;
+  sylph_config cfg;
+  bool finalized = false;
+  int64_t bytes = 0;
+  std::vector<void*> allocs;
+  std::map<std::string, HostTensor> host_w;
+  // packed model
+  float* stem_w = nullptr;  // fp32 [7][7][3][64]
+  float *stem_scale = nullptr, *stem_shift = nullptr;
+  struct Block { ConvLayer c1, c2, c3, sc; bool has_sc = false; };
+  std::vector<std::vector<Block>> stages;  // res2..res5
+  ConvLayer fpn_lat[3], fpn_out[3], p6, p7;  // index 0..2 = stage 3..5
+  std::vector<ConvLayer> cls_tower, box_tower;
+  std::vector<GNLayer> cls_gn, box_gn;
+  ConvLayer pred;  // bbox_pred(4) + ctrness(1) + iou_overlap(1)
+  std::vector<float> level_scales;
+  std::vector<ConvLayer> cg_tower;
+  std::vector<GNLayer> cg_gn;
+  ConvLayer cg_cls, cg_bias;
+  GNLayer cg_post;
+  float cg_conv_scale = 1.f, cg_bias_scale = 1.f;
+  bool has_backbone = false, has_head = false, has_codegen = false;
+  // plans
+  std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
+  Plan* cur = nullptr;
+
+  int dalloc(void** p, size_t n) {
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(p, n);
+    if (e != hipSuccess) return fail(std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
+    allocs.push_back(*p);
+    bytes += (int64_t)n;
+    return 0;
+  }
+  size_t esz() const { return dt == DT_BF16 ? 2 : 4; }
+};
+
+struct Plan {
+  int B = 0, H = 0, W = 0;
+  int hl[8], wl[8], off[8], Ltot = 0;
+  std::vector<int> img_h, img_w;
+  // backbone
+  void *x0 = nullptr, *stem_out = nullptr, *pool_out = nullptr;
+  void* F = nullptr;  // pyramid [B*Ltot][256]
+  std::vector<OpFn> backbone_ops, head_ops, support_ops;
+  bool backbone_built = false, head_built = false, support_built = false;
+  ImageDesc* img_desc_dev = nullptr;
+  ImageDesc* img_desc_host = nullptr;
+  // head
+  void *tA = nullptr, *tB = nullptr, *tC = nullptr, *tD = nullptr;
+  void* cls_feat = nullptr;  // output of the cls tower (input of the class-conditional conv)
+  float* pred = nullptr;    // [rows][8]
+  float* logits = nullptr;  // [rows][logits_ld]
+  int logits_ld = 0, logits_cap_ld = 0, ncls = 0;
+  void* code_w = nullptr;   // packed class codes [Npad][256]
+  int code_w_cap = 0;
+  const SegDesc* head_segs = nullptr;
+  const int2 *head_tiles = nullptr, *head_tiles32 = nullptr;
+  int head_mtiles = 0, head_BM = 128, head_mtiles32 = 0;
+  RowSeg* head_rowsegs = nullptr;
+  float* gn_partial = nullptr;
+  float2* gn_stats = nullptr;
+  // decode
+  DecodeSeg* dsegs = nullptr;
+  DecodeBuffers dbuf;
+  bool decode_built = false;
+  int cand_cap = 0, pool_cap = 0;
+  ImageOut* img_out_dev = nullptr;
+  ImageOut* img_out_host = nullptr;
+  // support
+  LevelDesc* lv_dev = nullptr;
+  void *roi = nullptr, *cgA = nullptr, *cgB = nullptr;
+  float *cg_conv_out = nullptr, *cg_bias_out = nullptr;
+  const float* cur_boxes = nullptr;
+  float* cur_code_out = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------
+static int upload(sylph_ctx* c, void** dev, const void* host, size_t n) {
+  RET(c->dalloc(dev, n));
+  HIPCHK(hipMemcpy(*dev, host, n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static const HostTensor* find_w(sylph_ctx* c, const std::string& k) {
+  auto it = c->host_w.find(k);
+  return it == c->host_w.end() ? nullptr : &it->second;
+}
+
+// pack (Cout,Cin,KH,KW) fp32 -> [Cout_pad][KH][KW][Cin] compute dtype; several tensors may be stacked on Cout
+static int pack_conv(sylph_ctx* c, const std::vector<const HostTensor*>& ws, ConvLayer* L) {
+  const HostTensor* w0 = ws[0];
+  if (w0->shape.size() != 4) return fail("conv weight must be 4-D");
+  const int Cin = (int)w0->shape[1], KH = (int)w0->shape[2], KW = (int)w0->shape[3];
+  int Cout = 0;
+  for (auto* w : ws) {
+    if ((int)w->shape[1] != Cin || (int)w->shape[2] != KH || (int)w->shape[3] != KW) return fail("stacked conv mismatch");
+    Cout += (int)w->shape[0];
+  }
+  const int pad_to = Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32);
+  const int Cout_pad = (Cout + pad_to - 1) / pad_to * pad_to;
+  const size_t K = (size_t)KH * KW * Cin;
+  std::vector<float> packed((size_t)Cout_pad * K, 0.f);
+  int n0 = 0;
+  for (auto* w : ws) {
+    const int co = (int)w->shape[0];
+    for (int n = 0; n < co; ++n)
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int kh = 0; kh < KH; ++kh)
+          for (int kw = 0; kw < KW; ++kw)
+            packed[(size_t)(n0 + n) * K + ((size_t)kh * KW + kw) * Cin + ci] =
+                w->data[(((size_t)n * Cin + ci) * KH + kh) * KW + kw];
+    n0 += co;
+  }
+  L->Cin = Cin; L->Cout = Cout; L->Cout_pad = Cout_pad; L->KH = KH; L->KW = KW;
+  if (c->dt == DT_BF16) {
+    std::vector<uint16_t> h(packed.size());
+    for (size_t i = 0; i < packed.size(); ++i) h[i] = f2bf_host(packed[i]);
+    RET(upload(c, &L->w, h.data(), h.size() * 2));
+  } else {
+    RET(upload(c, &L->w, packed.data(), packed.size() * 4));
+  }
+  return 0;
+}
+
+static int upload_vec(sylph_ctx* c, float** dev, const std::vector<float>& v, int pad_to) {
+  std::vector<float> t(v);
+  t.resize((size_t)pad_to, 0.f);
+  return upload(c, (void**)dev, t.data(), t.size() * 4);
+}
+
+// conv + FrozenBN folded into per-channel scale/shift (detectron2 FrozenBatchNorm2d, eps 1e-5)
+static int make_conv_bn(sylph_ctx* c, const std::string& name, ConvLayer* L) {
+  const HostTensor* w = find_w(c, name + ".weight");
+  const HostTensor *g = find_w(c, name + ".norm.weight"), *b = find_w(c, name + ".norm.bias");
+  const HostTensor *rm = find_w(c, name + ".norm.running_mean"), *rv = find_w(c, name + ".norm.running_var");
+  if (!w || !g || !b || !rm || !rv) return fail("missing weights for " + name);
+  RET(pack_conv(c, {w}, L));
+  std::vector<float> sc(L->Cout), sh(L->Cout);
+  for (int i = 0; i < L->Cout; ++i) {
+    const float s = g->data[i] * (1.0f / sqrtf(rv->data[i] + 1e-5f));
+    sc[i] = s;
+    sh[i] = b->data[i] - rm->data[i] * s;
+  }
+  RET(upload_vec(c, &L->scale, sc, L->Cout_pad));
+  RET(upload_vec(c, &L->shift, sh, L->Cout_pad));
+  return 0;
+}
+
+static int make_conv_bias(sylph_ctx* c, const std::vector<std::string>& names, ConvLayer* L) {
+  std::vector<const HostTensor*> ws;
+  std::vector<float> bias;
+  for (auto& n : names) {
+    const HostTensor *w = find_w(c, n + ".weight"), *b = find_w(c, n + ".bias");
+    if (!w || !b) return fail("missing weights for " + n);
+    ws.push_back(w);
+    bias.insert(bias.end(), b->data.begin(), b->data.end());
+  }
+  RET(pack_conv(c, ws, L));
+  RET(upload_vec(c, &L->shift, bias, L->Cout_pad));
+  return 0;
+}
+
+static int make_gn(sylph_ctx* c, const std::string& name, GNLayer* G) {
+  const HostTensor *g = find_w(c, name + ".weight"), *b = find_w(c, name + ".bias");
+  if (!g || !b) return fail("missing weights for " + name);
+  if (g->data.size() != 256) return fail("GroupNorm layers must have 256 channels: " + name);
+  RET(upload_vec(c, &G->gamma, g->data, 256));
+  RET(upload_vec(c, &G->beta, b->data, 256));
+  return 0;
+}
+
+static bool has_prefix(sylph_ctx* c, const std::string& p) {
+  auto it = c->host_w.lower_bound(p);
+  return it != c->host_w.end() && it->first.compare(0, p.size(), p) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void level_dims(const sylph_config& cfg, int H, int W, int* hl, int* wl, int* off, int* Ltot) {
+  // stride 8/16/32 from the bottom-up path, then P6/P7 by 3x3 s2 p1 convs (ceil(x/2))
+  int h = H / 8, w = W / 8;
+  int o = 0;
+  for (int l = 0; l < cfg.nlevels; ++l) {
+    hl[l] = h; wl[l] = w; off[l] = o;
+    o += h * w;
+    if (l < 2) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+    else { h = (h + 1) / 2; w = (w + 1) / 2; }
+  }
+  *Ltot = o;
+}
+
+struct Geom {
+  const SegDesc* segs;
+  const int2* tiles;
+  int n_mtiles;
+};
+
+static int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geom* g) {
+  std::vector<int2> tiles;
+  for (size_t s = 0; s < segs.size(); ++s) {
+    const int rows = segs[s].out_H * segs[s].out_W;
+    for (int r = 0; r < rows; r += BM) tiles.push_back(make_int2((int)s, r));
+  }
+  void *ds = nullptr, *dtl = nullptr;
+  RET(upload(c, &ds, segs.data(), segs.size() * sizeof(SegDesc)));
+  RET(upload(c, &dtl, tiles.data(), tiles.size() * sizeof(int2)));
+  g->segs = (const SegDesc*)ds;
+  g->tiles = (const int2*)dtl;
+  g->n_mtiles = (int)tiles.size();
+  return 0;
+}
+
+struct ConvOpts {
+  int stride = 1, pad = 0;
+  int relu_nch = 0, mul_nch = 0;
+  const void* res = nullptr;
+  int res_ld = 0, res_mode = 0;
+  int in_relu = 0;
+  bool out_f32 = false;
+  int cout_override = -1;  // logical Cout (class-conditional conv)
+};
+
+static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
+                    int out_ld, const std::vector<SegDesc>& segs, const ConvOpts& o) {
+  long rows = 0;
+  for (auto& s : segs) rows += (long)s.out_H * s.out_W;
+  int BM, BN;
+  conv_pick_tile((int)rows, L.Cout_pad, &BM, &BN);
+  if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
+  Geom g;
+  RET(make_geom(c, segs, BM, &g));
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.wt = L.w; a.out = out; a.res = o.res;
+  a.scale = L.scale; a.shift = L.shift;
+  a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;
+  a.Cin = L.Cin; a.Cout = o.cout_override >= 0 ? o.cout_override : L.Cout;
+  a.KH = L.KH; a.KW = L.KW; a.stride = o.stride; a.pad = o.pad;
+  a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
+  a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode; a.in_relu = o.in_relu;
+  const DType dt = c->dt;
+  const bool of32 = o.out_f32;
+  ops.push_back([a, BM, BN, dt, of32](hipStream_t s) { return launch_conv(dt, of32, a, BM, BN, s); });
+  return 0;
+}
+
+static std::vector<SegDesc> image_segs(int B, int Hin, int Win, int Hout, int Wout, int resH = 0, int resW = 0) {
+  std::vector<SegDesc> v((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    SegDesc s;
+    memset(&s, 0, sizeof(s));
+    s.in_row0 = b * Hin * Win; s.in_H = Hin; s.in_W = Win;
+    s.out_row0 = b * Hout * Wout; s.out_H = Hout; s.out_W = Wout;
+    s.res_H = resH ? resH : Hout; s.res_W = resW ? resW : Wout;
+    s.res_row0 = b * s.res_H * s.res_W;
+    s.mul = 1.f;
+    v[b] = s;
+  }
+  return v;
+}
+
+static Plan* get_plan(sylph_ctx* c, int B, int H, int W) {
+  auto key = std::make_tuple(B, H, W);
+  auto it = c->plans.find(key);
+  if (it != c->plans.end()) return it->second.get();
+  std::unique_ptr<Plan> p(new Plan());
+  p->B = B; p->H = H; p->W = W;
+  level_dims(c->cfg, H, W, p->hl, p->wl, p->off, &p->Ltot);
+  p->img_h.assign(B, H);
+  p->img_w.assign(B, W);
+  memset(&p->dbuf, 0, sizeof(p->dbuf));
+  Plan* raw = p.get();
+  c->plans[key] = std::move(p);
+  return raw;
+}
+
+static int ensure_pyramid(sylph_ctx* c, Plan* P) {
+  if (!P->F) RET(c->dalloc(&P->F, (size_t)P->B * P->Ltot * 256 * c->esz()));
+  return 0;
+}
+
+static int build_backbone(sylph_ctx* c, Plan* P) {
+  if (P->backbone_built) return 0;
+  if (!c->has_backbone) return fail("backbone weights were not loaded");
+  const int B = P->B, H = P->H, W = P->W;
+  const size_t e = c->esz();
+  RET(ensure_pyramid(c, P));
+  RET(c->dalloc(&P->x0, (size_t)B * H * W * 4 * e));
+  const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1;
+  const int H4 = (H2 - 1) / 2 + 1, W4 = (W2 - 1) / 2 + 1;
+  RET(c->dalloc(&P->stem_out, (size_t)B * H2 * W2 * 64 * e));
+  RET(c->dalloc(&P->pool_out, (size_t)B * H4 * W4 * 64 * e));
+  RET(c->dalloc((void**)&P->img_desc_dev, sizeof(ImageDesc) * B));
+  HIPCHK(hipHostMalloc((void**)&P->img_desc_host, sizeof(ImageDesc) * B));
+  auto& ops = P->backbone_ops;
+  const DType dt = c->dt;
+  {
+    void *x0 = P->x0, *so = P->stem_out, *po = P->pool_out;
+    const float *sw = c->stem_w, *ss = c->stem_scale, *sh = c->stem_shift;
+    ops.push_back([=](hipStream_t s) { return launch_stem(dt, x0, sw, ss, sh, so, B, H, W, H2, W2, s); });
+    ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
+  }
+  const void* X = P->pool_out;
+  int Hin = H4, Win = W4, Cin = 64;
+  const void* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_h[4], stage_w[4];
+  for (int si = 0; si < 4; ++si) {
+    const int mid = 64 << si, cout = 256 << si;
+    const int first_stride = si == 0 ? 1 : 2;
+    const int Hs = (Hin - 1) / first_stride + 1, Ws = (Win - 1) / first_stride + 1;
+    void *t1, *t2, *sc, *Ya, *Yb;
+    // t1 may still be at the input resolution when the stride sits on the 3x3
+    RET(c->dalloc(&t1, (size_t)B * Hin * Win * mid * e));
+    RET(c->dalloc(&t2, (size_t)B * Hs * Ws * mid * e));
+    RET(c->dalloc(&sc, (size_t)B * Hs * Ws * cout * e));
+    RET(c->dalloc(&Ya, (size_t)B * Hs * Ws * cout * e));
+    RET(c->dalloc(&Yb, (size_t)B * Hs * Ws * cout * e));
+    auto& blocks = c->stages[si];
+    void* Y = nullptr;
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+      const auto& blk = blocks[bi];
+      const int stride = bi == 0 ? first_stride : 1;
+      const int s1 = c->cfg.stride_in_1x1 ? stride : 1, s3 = c->cfg.stride_in_1x1 ? 1 : stride;
+      const int H1 = (Hin - 1) / s1 + 1, W1 = (Win - 1) / s1 + 1;
+      const int Ho = (Hin - 1) / stride + 1, Wo = (Win - 1) / stride + 1;
+      ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
+      RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
+      ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
+      RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
+      const void* resid = X;
+      if (blk.has_sc) {
+        ConvOpts os; os.stride = stride;
+        RET(add_conv(c, ops, blk.sc, X, Cin, sc, cout, image_segs(B, Hin, Win, Ho, Wo), os));
+        resid = sc;
+      }
+      Y = (Y == Ya) ? Yb : Ya;
+      ConvOpts o3; o3.relu_nch = 1 << 30; o3.res = resid; o3.res_ld = cout; o3.res_mode = 1;
+      RET(add_conv(c, ops, blk.c3, t2, mid, Y, cout, image_segs(B, Ho, Wo, Ho, Wo), o3));
+      X = Y; Hin = Ho; Win = Wo; Cin = cout;
+    }
+    stage_out[si] = X; stage_h[si] = Hin; stage_w[si] = Win;
+  }
+  // FPN (res3..res5 -> p3..p5), top-down with nearest 2x upsample fused as a residual, then P6/P7
+  void* lat[3] = {nullptr, nullptr, nullptr};
+  for (int k = 2; k >= 0; --k) {
+    const int si = k + 1, h = stage_h[si], w = stage_w[si], cin = 256 << si;
+    if (h != P->hl[k] || w != P->wl[k]) return fail("internal: level geometry mismatch");
+    RET(c->dalloc(&lat[k], (size_t)B * h * w * 256 * e));
+    ConvOpts ol;
+    std::vector<SegDesc> segs = image_segs(B, h, w, h, w);
+    if (k < 2) {
+      ol.res = lat[k + 1]; ol.res_ld = 256; ol.res_mode = 2;
+      segs = image_segs(B, h, w, h, w, stage_h[si + 1], stage_w[si + 1]);
+      if (h != 2 * stage_h[si + 1] || w != 2 * stage_w[si + 1]) return fail("FPN needs exact 2x level sizes");
+    }
+    RET(add_conv(c, ops, c->fpn_lat[k], stage_out[si], cin, lat[k], 256, segs, ol));
+    std::vector<SegDesc> so = image_segs(B, h, w, h, w);
+    for (int b = 0; b < B; ++b) so[b].out_row0 = b * P->Ltot + P->off[k];
+    ConvOpts oo; oo.pad = 1;
+    RET(add_conv(c, ops, c->fpn_out[k], lat[k], 256, P->F, 256, so, oo));
+  }
+  for (int k = 3; k < c->cfg.nlevels && k < 5; ++k) {
+    std::vector<SegDesc> sg = image_segs(B, P->hl[k - 1], P->wl[k - 1], P->hl[k], P->wl[k]);
+    for (int b = 0; b < B; ++b) {
+      sg[b].in_row0 = b * P->Ltot + P->off[k - 1];
+      sg[b].out_row0 = b * P->Ltot + P->off[k];
+    }
+    ConvOpts op; op.stride = 2; op.pad = 1; op.in_relu = (k == 4) ? 1 : 0;
+    RET(add_conv(c, ops, k == 3 ? c->p6 : c->p7, P->F, 256, P->F, 256, sg, op));
+  }
+  P->backbone_built = true;
+  return 0;
+}
+
+static std::vector<SegDesc> pyramid_segs(sylph_ctx* c, Plan* P) {
+  std::vector<SegDesc> v;
+  for (int b = 0; b < P->B; ++b)
+    for (int l = 0; l < c->cfg.nlevels; ++l) {
+      SegDesc s;
+      memset(&s, 0, sizeof(s));
+      s.in_row0 = s.out_row0 = s.res_row0 = b * P->Ltot + P->off[l];
+      s.in_H = s.out_H = s.res_H = P->hl[l];
+      s.in_W = s.out_W = s.res_W = P->wl[l];
+      s.mul = c->cfg.use_scale ? c->level_scales[l] : 1.f;
+      v.push_back(s);
+    }
+  return v;
+}
+
+static int add_gn(sylph_ctx* c, Plan* P, std::vector<OpFn>& ops, void* x, const RowSeg* segs_dev, int nseg,
+                  int max_rows, const GNLayer& G, int relu) {
+  const DType dt = c->dt;
+  float* partial = P->gn_partial;
+  float2* stats = P->gn_stats;
+  const float *ga = G.gamma, *be = G.beta;
+  ops.push_back([=](hipStream_t s) {
+    return launch_groupnorm(dt, x, segs_dev, nseg, max_rows, 256, ga, be, 1e-5f, relu, partial, stats, s);
+  });
+  return 0;
+}
+
+static int ensure_gn_ws(sylph_ctx* c, Plan* P, int nseg, int max_rows) {
+  if (P->gn_partial) return 0;
+  const int max_chunks = (max_rows + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  RET(c->dalloc((void**)&P->gn_partial, (size_t)nseg * max_chunks * 32 * 3 * sizeof(float)));
+  RET(c->dalloc((void**)&P->gn_stats, (size_t)nseg * 32 * sizeof(float2)));
+  return 0;
+}
+
+static int build_head(sylph_ctx* c, Plan* P) {
+  if (P->head_built) return 0;
+  if (!c->has_head) return fail("FCOS head weights were not loaded");
+  RET(ensure_pyramid(c, P));
+  const size_t e = c->esz();
+  const size_t rows = (size_t)P->B * P->Ltot;
+  const int L = c->cfg.nlevels, nseg = P->B * L;
+  RET(c->dalloc(&P->tA, rows * 256 * e));
+  RET(c->dalloc(&P->tB, rows * 256 * e));
+  RET(c->dalloc(&P->tC, rows * 256 * e));
+  RET(c->dalloc(&P->tD, rows * 256 * e));
+  RET(c->dalloc((void**)&P->pred, rows * 8 * sizeof(float)));
+  std::vector<RowSeg> rs;
+  for (int b = 0; b < P->B; ++b)
+    for (int l = 0; l < L; ++l) rs.push_back(RowSeg{b * P->Ltot + P->off[l], P->hl[l] * P->wl[l]});
+  RET(upload(c, (void**)&P->head_rowsegs, rs.data(), rs.size() * sizeof(RowSeg)));
+  const int max_rows = P->hl[0] * P->wl[0];
+  // the support plan of the same shape may already own a GN workspace sized for fewer segments
+  if (P->gn_partial) { P->gn_partial = nullptr; P->gn_stats = nullptr; }
+  RET(ensure_gn_ws(c, P, nseg > P->B ? nseg : P->B, max_rows));
+  const std::vector<SegDesc> segs = pyramid_segs(c, P);
+  auto& ops = P->head_ops;
+  auto tower = [&](const std::vector<ConvLayer>& convs, const std::vector<GNLayer>& gns, void* b0, void* b1,
+                   void** last) -> int {
+    const void* in = P->F;
+    void* out = b0;
+    for (size_t i = 0; i < convs.size(); ++i) {
+      ConvOpts o; o.pad = 1;
+      RET(add_conv(c, ops, convs[i], in, 256, out, 256, segs, o));
+      RET(add_gn(c, P, ops, out, P->head_rowsegs, nseg, max_rows, gns[i], 1));
+      in = out;
+      out = (out == b0) ? b1 : b0;
+    }
+    *last = const_cast<void*>(in);
+    return 0;
+  };
+  void *cls_feat = nullptr, *box_feat = nullptr;
+  RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat));
+  RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat));
+  ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
+  RET(add_conv(c, ops, c->pred, box_feat, 256, P->pred, 8, segs, op));
+  // geometry for the class-conditional 1x1 conv (weights arrive per call)
+  {
+    Geom g;
+    int BM, BN;
+    conv_pick_tile((int)rows, 128, &BM, &BN);
+    RET(make_geom(c, segs, BM, &g));
+    P->head_segs = g.segs; P->head_tiles = g.tiles; P->head_mtiles = g.n_mtiles; P->head_BM = BM;
+    Geom g32;
+    RET(make_geom(c, segs, 128, &g32));
+    P->head_tiles32 = g32.tiles; P->head_mtiles32 = g32.n_mtiles;
+  }
+  P->cls_feat = cls_feat;
+  P->head_built = true;
+  return 0;
+}
+
+static int build_decode(sylph_ctx* c, Plan* P) {
+  if (P->decode_built) return 0;
+  const int L = c->cfg.nlevels, B = P->B, nseg = B * L;
+  std::vector<DecodeSeg> ds;
+  for (int b = 0; b < B; ++b) {
+    unsigned lb = 0;
+    for (int l = 0; l < L; ++l) {
+      DecodeSeg d;
+      d.row0 = b * P->Ltot + P->off[l]; d.nloc = P->hl[l] * P->wl[l]; d.W = P->wl[l];
+      d.stride = c->cfg.strides[l]; d.level = l; d.image = b; d.loc_base = lb; d.pad = 0;
+      lb += (unsigned)d.nloc;
+      ds.push_back(d);
+    }
+  }
+  RET(upload(c, (void**)&P->dsegs, ds.data(), ds.size() * sizeof(DecodeSeg)));
+  int pool = 64;
+  while (pool < L * c->cfg.pre_nms_topk) pool <<= 1;
+  if (pool > 8192) return fail("levels * PRE_NMS_TOPK exceeds the 8192-entry on-chip sort capacity");
+  P->pool_cap = pool;
+  P->cand_cap = c->cfg.cand_cap > 0 ? c->cfg.cand_cap : 65536;
+  DecodeBuffers& d = P->dbuf;
+  RET(c->dalloc((void**)&d.cand_key, (size_t)nseg * P->cand_cap * 4));
+  RET(c->dalloc((void**)&d.cand_idx, (size_t)nseg * P->cand_cap * 4));
+  RET(c->dalloc((void**)&d.cand_count, (size_t)nseg * 4));
+  RET(c->dalloc((void**)&d.pool_key, (size_t)B * pool * 8));
+  RET(c->dalloc((void**)&d.pool_count, (size_t)B * 4));
+  RET(c->dalloc((void**)&d.s_box, (size_t)B * pool * 16));
+  RET(c->dalloc((void**)&d.s_score, (size_t)B * pool * 4));
+  RET(c->dalloc((void**)&d.s_cls, (size_t)B * pool * 4));
+  RET(c->dalloc((void**)&d.s_level, (size_t)B * pool * 4));
+  RET(c->dalloc((void**)&d.s_loc, (size_t)B * pool * 8));
+  RET(c->dalloc((void**)&d.s_ord, (size_t)B * pool * 4));
+  RET(c->dalloc((void**)&d.mask, (size_t)B * pool * (pool / 64) * 8));
+  RET(c->dalloc((void**)&d.status, 4));
+  RET(c->dalloc((void**)&P->img_out_dev, sizeof(ImageOut) * B));
+  HIPCHK(hipHostMalloc((void**)&P->img_out_host, sizeof(ImageOut) * B));
+  P->decode_built = true;
+  return 0;
+}
+
+static int build_support(sylph_ctx* c, Plan* P) {
+  if (P->support_built) return 0;
+  if (!c->has_codegen) return fail("code generator weights were not loaded");
+  RET(ensure_pyramid(c, P));
+  const size_t e = c->esz();
+  const int S = P->B, L = c->cfg.nlevels, npos = 49;
+  std::vector<LevelDesc> lv;
+  for (int b = 0; b < S; ++b)
+    for (int l = 0; l < L; ++l)
+      lv.push_back(LevelDesc{b * P->Ltot + P->off[l], P->hl[l], P->wl[l], 1.0f / (float)c->cfg.strides[l]});
+  RET(upload(c, (void**)&P->lv_dev, lv.data(), lv.size() * sizeof(LevelDesc)));
+  RET(c->dalloc(&P->roi, (size_t)S * npos * 256 * e));
+  RET(c->dalloc(&P->cgA, (size_t)S * npos * 256 * e));
+  RET(c->dalloc(&P->cgB, (size_t)S * npos * 256 * e));
+  RET(c->dalloc((void**)&P->cg_conv_out, (size_t)S * npos * 256 * 4));
+  RET(c->dalloc((void**)&P->cg_bias_out, (size_t)S * npos * 4));
+  RET(ensure_gn_ws(c, P, S, P->hl[0] * P->wl[0]));
+  std::vector<RowSeg> rs;
+  for (int s = 0; s < S; ++s) rs.push_back(RowSeg{s * npos, npos});
+  RowSeg* rs_dev = nullptr;
+  RET(upload(c, (void**)&rs_dev, rs.data(), rs.size() * sizeof(RowSeg)));
+  const std::vector<SegDesc> segs = image_segs(S, 7, 7, 7, 7);
+  auto& ops = P->support_ops;
+  const DType dt = c->dt;
+  Plan* PP = P;
+  {
+    const void* F = P->F;
+    const LevelDesc* lvd = P->lv_dev;
+    void* roi = P->roi;
+    ops.push_back([=](hipStream_t s) { return launch_roi_align(dt, F, 256, lvd, L, PP->cur_boxes, S, 7, roi, s); });
+  }
+  const void* in = P->roi;
+  void* out = P->cgA;
+  for (size_t i = 0; i < c->cg_tower.size(); ++i) {
+    ConvOpts o; o.pad = 1;
+    RET(add_conv(c, ops, c->cg_tower[i], in, 256, out, 256, segs, o));
+    RET(add_gn(c, P, ops, out, rs_dev, S, npos, c->cg_gn[i], 1));
+    in = out;
+    out = (out == P->cgA) ? P->cgB : P->cgA;
+  }
+  ConvOpts oc; oc.pad = 1; oc.out_f32 = true;
+  RET(add_conv(c, ops, c->cg_cls, in, 256, P->cg_conv_out, 256, segs, oc));
+  const int has_bias = c->cfg.cg_has_bias;
+  if (has_bias) RET(add_conv(c, ops, c->cg_bias, in, 256, P->cg_bias_out, 1, segs, oc));
+  {
+    const float *co = P->cg_conv_out, *bo = P->cg_bias_out;
+    const int l2 = c->cfg.cg_bias_l2_norm;
+    ops.push_back([=](hipStream_t s) {
+      return launch_codegen_tail(co, 256, bo, 1, S, npos, 256, l2, has_bias, PP->cur_code_out, s);
+    });
+  }
+  P->support_built = true;
+  return 0;
+}
+
+static int run_ops(sylph_ctx* c, const std::vector<OpFn>& ops, const char* what) {
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const int r = ops[i](c->stream);
+    if (r != 0) return fail(std::string(what) + ": op " + std::to_string(i) + " failed with " + std::to_string(r));
+  }
+  return 0;
+}
+
+// ================================================================================================
+extern "C" {
+
+void sylph_config_default(sylph_config* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->resnet_depth = 50; cfg->stride_in_1x1 = 1; cfg->num_cls_convs = 4; cfg->num_box_convs = 4;
+  cfg->nlevels = 5;
+  const int st[5] = {8, 16, 32, 64, 128};
+  for (int i = 0; i < 5; ++i) cfg->strides[i] = st[i];
+  cfg->pixel_mean[0] = 103.530f; cfg->pixel_mean[1] = 116.280f; cfg->pixel_mean[2] = 123.675f;
+  cfg->pixel_std[0] = cfg->pixel_std[1] = cfg->pixel_std[2] = 1.f;
+  cfg->size_divisibility = 32; cfg->use_scale = 1; cfg->cond_use_bias = 1;
+  cfg->pre_nms_thresh = 0.05f; cfg->pre_nms_topk = 1000; cfg->nms_thresh = 0.6f; cfg->post_nms_topk = 100;
+  cfg->thresh_with_ctr = 0; cfg->quality_mode = 0;
+  cfg->cg_tower_layers = 2; cfg->cg_has_bias = 1; cfg->cg_bias_l2_norm = 0; cfg->cg_post_norm = 1;
+  cfg->cg_conv_l2_norm = 1; cfg->cg_use_weight_scale = 1; cfg->prior_prob = 0.01f; cfg->cand_cap = 0;
+}
+
+const char* sylph_last_error(void) { return g_err.c_str(); }
+
+int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out) {
+  if (!out) return fail("out is NULL");
+  if (dtype != SYLPH_F32 && dtype != SYLPH_BF16) return fail("dtype must be SYLPH_F32 or SYLPH_BF16");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device_id < 0 || device_id >= n) return fail("no such HIP device: " + std::to_string(device_id));
+  HIPCHK(hipSetDevice(device_id));
+  sylph_ctx* c = new sylph_ctx();
+  c->device = device_id;
+  c->dt = dtype == SYLPH_BF16 ? DT_BF16 : DT_F32;
+  sylph_config_default(&c->cfg);
+  *out = c;
+  return 0;
+}
+
+void sylph_ctx_destroy(sylph_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (auto& kv : c->plans) {
+    if (kv.second->img_desc_host) hipHostFree(kv.second->img_desc_host);
+    if (kv.second->img_out_host) hipHostFree(kv.second->img_out_host);
+  }
+  for (void* p : c->allocs) hipFree(p);
+  delete c;
+}
+
+int sylph_set_stream(sylph_ctx* c, void* s) {
+  c->stream = (hipStream_t)s;
+  return 0;
+}
+
+int sylph_set_config(sylph_ctx* c, const sylph_config* cfg) {
+  if (c->finalized) return fail("sylph_set_config must precede sylph_finalize_weights");
+  if (cfg->nlevels != 5) return fail("only the 5-level FCOS pyramid (p3..p7) is supported");
+  if (cfg->resnet_depth != 50 && cfg->resnet_depth != 101 && cfg->resnet_depth != 152)
+    return fail("MODEL.RESNETS.DEPTH must be 50, 101 or 152");
+  c->cfg = *cfg;
+  return 0;
+}
+
+int sylph_load_weight(sylph_ctx* c, const char* name, const float* data, const int64_t* shape, int ndim) {
+  if (c->finalized) return fail("weights already finalized");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(data, data + n);
+  c->host_w[name] = std::move(t);
+  return 0;
+}
+
+int sylph_finalize_weights(sylph_ctx* c) {
+  if (c->finalized) return fail("weights already finalized");
+  HIPCHK(hipSetDevice(c->device));
+  const std::string bu = "backbone.bottom_up";
+  if (has_prefix(c, bu + ".stem")) {
+    const HostTensor* w = find_w(c, bu + ".stem.conv1.weight");
+    const HostTensor *g = find_w(c, bu + ".stem.conv1.norm.weight"), *b = find_w(c, bu + ".stem.conv1.norm.bias");
+    const HostTensor *rm = find_w(c, bu + ".stem.conv1.norm.running_mean"),
+                     *rv = find_w(c, bu + ".stem.conv1.norm.running_var");
+    if (!w || !g || !b || !rm || !rv) return fail("missing stem weights");
+    if (w->shape[0] != 64 || w->shape[1] != 3 || w->shape[2] != 7 || w->shape[3] != 7) return fail("stem must be 64x3x7x7");
+    std::vector<float> pk(7 * 7 * 3 * 64);
+    for (int n = 0; n < 64; ++n)
+      for (int ci = 0; ci < 3; ++ci)
+        for (int kh = 0; kh < 7; ++kh)
+          for (int kw = 0; kw < 7; ++kw)
+            pk[((kh * 7 + kw) * 3 + ci) * 64 + n] = w->data[((n * 3 + ci) * 7 + kh) * 7 + kw];
+    RET(upload(c, (void**)&c->stem_w, pk.data(), pk.size() * 4));
+    std::vector<float> sc(64), sh(64);
+    for (int i = 0; i < 64; ++i) {
+      sc[i] = g->data[i] * (1.0f / sqrtf(rv->data[i] + 1e-5f));
+      sh[i] = b->data[i] - rm->data[i] * sc[i];
+    }
+    RET(upload_vec(c, &c->stem_scale, sc, 64));
+    RET(upload_vec(c, &c->stem_shift, sh, 64));
+    const int nb50[4] = {3, 4, 6, 3}, nb101[4] = {3, 4, 23, 3}, nb152[4] = {3, 8, 36, 3};
+    const int* nb = c->cfg.resnet_depth == 50 ? nb50 : (c->cfg.resnet_depth == 101 ? nb101 : nb152);
+    c->stages.resize(4);
+    for (int si = 0; si < 4; ++si) {
+      c->stages[si].resize(nb[si]);
+      for (int bi = 0; bi < nb[si]; ++bi) {
+        const std::string q = bu + ".res" + std::to_string(si + 2) + "." + std::to_string(bi);
+        auto& blk = c->stages[si][bi];
+        RET(make_conv_bn(c, q + ".conv1", &blk.c1));
+        RET(make_conv_bn(c, q + ".conv2", &blk.c2));
+        RET(make_conv_bn(c, q + ".conv3", &blk.c3));
+        blk.has_sc = bi == 0;
+        if (blk.has_sc) RET(make_conv_bn(c, q + ".shortcut", &blk.sc));
+      }
+    }
+    for (int k = 0; k < 3; ++k) {
+      RET(make_conv_bias(c, {"backbone.fpn_lateral" + std::to_string(k + 3)}, &c->fpn_lat[k]));
+      RET(make_conv_bias(c, {"backbone.fpn_output" + std::to_string(k + 3)}, &c->fpn_out[k]));
+    }
+    RET(make_conv_bias(c, {"backbone.top_block.p6"}, &c->p6));
+    RET(make_conv_bias(c, {"backbone.top_block.p7"}, &c->p7));
+    c->has_backbone = true;
+  }
+  const std::string hp = "proposal_generator.fcos_head";
+  if (has_prefix(c, hp)) {
+    c->cls_tower.resize(c->cfg.num_cls_convs); c->cls_gn.resize(c->cfg.num_cls_convs);
+    c->box_tower.resize(c->cfg.num_box_convs); c->box_gn.resize(c->cfg.num_box_convs);
+    for (int i = 0; i < c->cfg.num_cls_convs; ++i) {
+      RET(make_conv_bias(c, {hp + ".cls_tower." + std::to_string(3 * i)}, &c->cls_tower[i]));
+      RET(make_gn(c, hp + ".cls_tower." + std::to_string(3 * i + 1), &c->cls_gn[i]));
+    }
+    for (int i = 0; i < c->cfg.num_box_convs; ++i) {
+      RET(make_conv_bias(c, {hp + ".bbox_tower." + std::to_string(3 * i)}, &c->box_tower[i]));
+      RET(make_gn(c, hp + ".bbox_tower." + std::to_string(3 * i + 1), &c->box_gn[i]));
+    }
+    RET(make_conv_bias(c, {hp + ".bbox_pred", hp + ".ctrness", hp + ".iou_overlap"}, &c->pred));
+    c->level_scales.assign(c->cfg.nlevels, 1.f);
+    if (c->cfg.use_scale)
+      for (int l = 0; l < c->cfg.nlevels; ++l) {
+        const HostTensor* s = find_w(c, hp + ".scales." + std::to_string(l) + ".scale");
+        if (!s) return fail("missing " + hp + ".scales." + std::to_string(l) + ".scale");
+        c->level_scales[l] = s->data[0];
+      }
+    c->has_head = true;
+  }
+  const std::string cp = "code_generator.code_generator_head";
+  if (has_prefix(c, cp)) {
+    c->cg_tower.resize(c->cfg.cg_tower_layers); c->cg_gn.resize(c->cfg.cg_tower_layers);
+    for (int i = 0; i < c->cfg.cg_tower_layers; ++i) {
+      RET(make_conv_bias(c, {cp + ".support_set_shared_tower." + std::to_string(3 * i)}, &c->cg_tower[i]));
+      RET(make_gn(c, cp + ".support_set_shared_tower." + std::to_string(3 * i + 1), &c->cg_gn[i]));
+    }
+    RET(make_conv_bias(c, {cp + ".support_set_cls_conv.0"}, &c->cg_cls));
+    if (c->cfg.cg_has_bias) RET(make_conv_bias(c, {cp + ".support_set_cls_bias.0"}, &c->cg_bias));
+    if (c->cfg.cg_post_norm) RET(make_gn(c, cp + ".post_norm", &c->cg_post));
+    // conv_scale exists iff USE_WEIGHT_SCALE and (CONV_L2_NORM or POST_NORM)  (code_generator.py:372-374)
+    c->cg_conv_scale = 1.f;
+    if (c->cfg.cg_use_weight_scale && (c->cfg.cg_conv_l2_norm || c->cfg.cg_post_norm)) {
+      const HostTensor* s = find_w(c, cp + ".conv_scale.scale");
+      if (!s) return fail("missing " + cp + ".conv_scale.scale");
+      c->cg_conv_scale = s->data[0];
+    }
+    c->cg_bias_scale = 1.f;
+    if (c->cfg.cg_has_bias) {
+      const HostTensor* s = find_w(c, cp + ".bias_scale.scale");
+      if (!s) return fail("missing " + cp + ".bias_scale.scale");
+      c->cg_bias_scale = s->data[0];
+    }
+    c->has_codegen = true;
+  }
+  c->host_w.clear();
+  c->finalized = true;
+  return 0;
+}
+
+int sylph_preprocess(sylph_ctx* c, int B, const float* const* images, const int* hs, const int* ws, int* ph, int* pw) {
+  if (!c->finalized) return fail("weights not finalized");
+  if (B <= 0) return fail("empty batch");
+  HIPCHK(hipSetDevice(c->device));
+  int mh = 0, mw = 0;
+  for (int b = 0; b < B; ++b) { mh = hs[b] > mh ? hs[b] : mh; mw = ws[b] > mw ? ws[b] : mw; }
+  const int d = c->cfg.size_divisibility;
+  if (d > 1) { mh = (mh + d - 1) / d * d; mw = (mw + d - 1) / d * d; }
+  Plan* P = get_plan(c, B, mh, mw);
+  RET(build_backbone(c, P));
+  // the previous batch's copy of the descriptor table must have been consumed
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int b = 0; b < B; ++b) {
+    P->img_desc_host[b].ptr = images[b]; P->img_desc_host[b].h = hs[b]; P->img_desc_host[b].w = ws[b];
+    P->img_h[b] = hs[b]; P->img_w[b] = ws[b];
+  }
+  HIPCHK(hipMemcpyAsync(P->img_desc_dev, P->img_desc_host, sizeof(ImageDesc) * B, hipMemcpyHostToDevice, c->stream));
+  KCHK(launch_preprocess(c->dt, P->img_desc_dev, P->x0, B, mh, mw, c->cfg.pixel_mean, c->cfg.pixel_std, c->stream),
+       "preprocess");
+  c->cur = P;
+  if (ph) *ph = mh;
+  if (pw) *pw = mw;
+  return 0;
+}
+
+int sylph_backbone_fpn(sylph_ctx* c) {
+  if (!c->cur || !c->cur->backbone_built) return fail("sylph_preprocess must be called first");
+  return run_ops(c, c->cur->backbone_ops, "backbone_fpn");
+}
+
+int sylph_import_pyramid(sylph_ctx* c, int B, int H, int W, const int* hs, const int* ws, const float* const* levels) {
+  if (!c->finalized) return fail("weights not finalized");
+  HIPCHK(hipSetDevice(c->device));
+  Plan* P = get_plan(c, B, H, W);
+  RET(ensure_pyramid(c, P));
+  for (int b = 0; b < B; ++b) { P->img_h[b] = hs ? hs[b] : H; P->img_w[b] = ws ? ws[b] : W; }
+  for (int l = 0; l < c->cfg.nlevels; ++l) {
+    const int hw = P->hl[l] * P->wl[l];
+    for (int b = 0; b < B; ++b)
+      KCHK(launch_import_nchw(c->dt, levels[l] + (size_t)b * 256 * hw, P->F, 256, hw, b * P->Ltot + P->off[l], 256,
+                              c->stream),
+           "import_pyramid");
+  }
+  c->cur = P;
+  return 0;
+}
+
+int sylph_export_pyramid(sylph_ctx* c, int level, float* out) {
+  Plan* P = c->cur;
+  if (!P || !P->F) return fail("no current batch");
+  if (level < 0 || level >= c->cfg.nlevels) return fail("bad level");
+  const int hw = P->hl[level] * P->wl[level];
+  for (int b = 0; b < P->B; ++b)
+    KCHK(launch_export_nchw(c->dt, P->F, out + (size_t)b * 256 * hw, 256, hw, b * P->Ltot + P->off[level], 256,
+                            c->stream),
+         "export_pyramid");
+  return 0;
+}
+
+int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, int N) {
+  Plan* P = c->cur;
+  if (!P) return fail("no current batch");
+  if (N <= 0) return fail("class_code is empty");
+  if (!cls_conv) return fail("cls_conv is NULL");
+  RET(build_head(c, P));
+  const size_t rows = (size_t)P->B * P->Ltot;
+  const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
+  const int Npad = (N + bn - 1) / bn * bn;
+  if (Npad > P->logits_cap_ld) {
+    RET(c->dalloc((void**)&P->logits, rows * Npad * sizeof(float)));
+    P->logits_cap_ld = Npad;
+  }
+  if (Npad > P->code_w_cap) {
+    RET(c->dalloc(&P->code_w, (size_t)Npad * 256 * c->esz()));
+    P->code_w_cap = Npad;
+  }
+  P->logits_ld = Npad;
+  P->ncls = N;
+  RET(run_ops(c, P->head_ops, "fcos_head"));
+  KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, c->stream), "pack_codes");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = P->cls_feat; a.wt = P->code_w; a.out = P->logits;
+  a.shift = (c->cfg.cond_use_bias && cls_bias) ? cls_bias : nullptr;
+  a.segs = P->head_segs;
+  int BM = P->head_BM;
+  if (bn == 32) { BM = 128; a.tiles = P->head_tiles32; a.n_mtiles = P->head_mtiles32; }
+  else { a.tiles = P->head_tiles; a.n_mtiles = P->head_mtiles; }
+  a.n_ntiles = Npad / bn;
+  a.Cin = 256; a.Cout = N; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.in_ld = 256; a.out_ld = Npad;
+  KCHK(launch_conv(c->dt, true, a, BM, bn, c->stream), "cond_cls_logits");
+  return 0;
+}
+
+int sylph_export_head(sylph_ctx* c, int level, float* logits, float* reg, float* ctr, float* iou) {
+  Plan* P = c->cur;
+  if (!P || !P->head_built || !P->logits) return fail("sylph_fcos_head must be called first");
+  if (level < 0 || level >= c->cfg.nlevels) return fail("bad level");
+  const int hw = P->hl[level] * P->wl[level];
+  for (int b = 0; b < P->B; ++b) {
+    const int row0 = b * P->Ltot + P->off[level];
+    if (logits)
+      KCHK(launch_export_nchw_f32(P->logits, logits + (size_t)b * P->ncls * hw, P->ncls, hw, row0, P->logits_ld, 0,
+                                  c->stream), "export logits");
+    if (reg) KCHK(launch_export_nchw_f32(P->pred, reg + (size_t)b * 4 * hw, 4, hw, row0, 8, 0, c->stream), "export reg");
+    if (ctr) KCHK(launch_export_nchw_f32(P->pred, ctr + (size_t)b * hw, 1, hw, row0, 8, 4, c->stream), "export ctr");
+    if (iou) KCHK(launch_export_nchw_f32(P->pred, iou + (size_t)b * hw, 1, hw, row0, 8, 5, c->stream), "export iou");
+  }
+  return 0;
+}
+
+int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, float* boxes, float* scores,
+                     int* classes, int* levels, float* locations, int* cand, int* counts, int* status) {
+  Plan* P = c->cur;
+  if (!P || !P->head_built || !P->logits) return fail("sylph_fcos_head must be called first");
+  if (max_out <= 0) return fail("max_out must be positive");
+  RET(build_decode(c, P));
+  HIPCHK(hipStreamSynchronize(c->stream));  // img_out_host reuse
+  for (int b = 0; b < P->B; ++b) {
+    const int H = oh ? oh[b] : P->img_h[b], W = ow ? ow[b] : P->img_w[b];
+    // detector_postprocess: python-double ratios cast to the fp32 tensor dtype
+    P->img_out_host[b].sx = (float)((double)W / (double)P->img_w[b]);
+    P->img_out_host[b].sy = (float)((double)H / (double)P->img_h[b]);
+    P->img_out_host[b].out_w = (float)W;
+    P->img_out_host[b].out_h = (float)H;
+  }
+  HIPCHK(hipMemcpyAsync(P->img_out_dev, P->img_out_host, sizeof(ImageOut) * P->B, hipMemcpyHostToDevice, c->stream));
+  DecodeCfg d;
+  d.num_classes = P->ncls; d.logits_ld = P->logits_ld; d.pre_nms_thresh = c->cfg.pre_nms_thresh;
+  d.pre_nms_topk = c->cfg.pre_nms_topk; d.nms_thresh = c->cfg.nms_thresh; d.post_nms_topk = c->cfg.post_nms_topk;
+  d.thresh_with_ctr = c->cfg.thresh_with_ctr; d.quality_mode = c->cfg.quality_mode; d.cand_cap = P->cand_cap;
+  d.pool_cap = P->pool_cap; d.nlevels = c->cfg.nlevels; d.max_out = max_out;
+  const int L = c->cfg.nlevels;
+  int nwb = (L * c->cfg.pre_nms_topk + 63) / 64;
+  if (nwb > P->pool_cap / 64) nwb = P->pool_cap / 64;
+  KCHK(launch_decode(d, P->dsegs, P->B * L, P->hl[0] * P->wl[0], P->B, nwb, P->logits, P->pred, 8, P->dbuf,
+                     P->img_out_dev, boxes, scores, classes, levels, locations, cand, counts, c->stream),
+       "decode_nms");
+  if (status) HIPCHK(hipMemcpyAsync(status, P->dbuf.status, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
+  Plan* P = c->cur;
+  if (!P) return fail("no current batch");
+  if (!boxes || !code_out) return fail("NULL argument");
+  RET(build_support(c, P));
+  P->cur_boxes = boxes;
+  P->cur_code_out = code_out;
+  return run_ops(c, P->support_ops, "codegen");
+}
+
+int sylph_normalize_codes(sylph_ctx* c, float* codes, int n) {
+  if (!c->has_codegen) return fail("code generator weights were not loaded");
+  if (n <= 0) return 0;
+  const float prior = -logf((1.f - c->cfg.prior_prob) / c->cfg.prior_prob);
+  KCHK(launch_normalize_codes(codes, n, 256, c->cg_post.gamma, c->cg_post.beta, c->cfg.cg_post_norm,
+                              c->cfg.cg_conv_l2_norm, c->cg_conv_scale, c->cg_bias_scale, prior, c->stream),
+       "normalize_codes");
+  return 0;
+}
+
+int sylph_conv2d(sylph_ctx* c, const float* x, int B, int C, int H, int W, const float* w_host, int Cout, int KH, int KW,
+                 int stride, int pad, const float* scale_host, const float* shift_host, int relu, const float* residual,
+                 float* y) {
+  HIPCHK(hipSetDevice(c->device));
+  const int bk = c->dt == DT_BF16 ? 64 : 32;
+  if (C % bk != 0) return fail("sylph_conv2d: Cin must be a multiple of " + std::to_string(bk));
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  sylph_ctx tmp;  // scratch allocations freed on return
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { hipStreamSynchronize(s); for (void* p : t->allocs) hipFree(p); } } guard{&tmp, c->stream};
+  HostTensor hw;
+  hw.shape = {Cout, C, KH, KW};
+  hw.data.assign(w_host, w_host + (size_t)Cout * C * KH * KW);
+  ConvLayer L;
+  RET(pack_conv(&tmp, {&hw}, &L));
+  if (scale_host) RET(upload_vec(&tmp, &L.scale, std::vector<float>(scale_host, scale_host + Cout), L.Cout_pad));
+  if (shift_host) RET(upload_vec(&tmp, &L.shift, std::vector<float>(shift_host, shift_host + Cout), L.Cout_pad));
+  void *xin, *yout, *res = nullptr;
+  RET(tmp.dalloc(&xin, (size_t)B * H * W * C * tmp.esz()));
+  RET(tmp.dalloc(&yout, (size_t)B * Ho * Wo * Cout * tmp.esz()));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_import_nchw(c->dt, x + (size_t)b * C * H * W, xin, C, H * W, b * H * W, C, c->stream), "import");
+  ConvOpts o; o.stride = stride; o.pad = pad; o.relu_nch = relu ? (1 << 30) : 0;
+  if (residual) {
+    RET(tmp.dalloc(&res, (size_t)B * Ho * Wo * Cout * tmp.esz()));
+    for (int b = 0; b < B; ++b)
+      KCHK(launch_import_nchw(c->dt, residual + (size_t)b * Cout * Ho * Wo, res, Cout, Ho * Wo, b * Ho * Wo, Cout,
+                              c->stream), "import");
+    o.res = res; o.res_ld = Cout; o.res_mode = 1;
+  }
+  std::vector<OpFn> ops;
+  RET(add_conv(&tmp, ops, L, xin, C, yout, Cout, image_segs(B, H, W, Ho, Wo), o));
+  RET(run_ops(c, ops, "conv2d"));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_export_nchw(c->dt, yout, y + (size_t)b * Cout * Ho * Wo, Cout, Ho * Wo, b * Ho * Wo, Cout, c->stream),
+         "export");
+  return 0;
+}
+
+int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const float* gamma_host, const float* beta_host,
+                     int relu, float* y) {
+  HIPCHK(hipSetDevice(c->device));
+  sylph_ctx tmp;
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { hipStreamSynchronize(s); for (void* p : t->allocs) hipFree(p); } } guard{&tmp, c->stream};
+  const int HW = H * W;
+  void* buf;
+  RET(tmp.dalloc(&buf, (size_t)B * HW * 256 * tmp.esz()));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_import_nchw(c->dt, x + (size_t)b * 256 * HW, buf, 256, HW, b * HW, 256, c->stream), "import");
+  std::vector<RowSeg> rs;
+  for (int b = 0; b < B; ++b) rs.push_back(RowSeg{b * HW, HW});
+  RowSeg* rsd;
+  RET(upload(&tmp, (void**)&rsd, rs.data(), rs.size() * sizeof(RowSeg)));
+  float *ga, *be, *partial;
+  float2* stats;
+  RET(upload_vec(&tmp, &ga, std::vector<float>(gamma_host, gamma_host + 256), 256));
+  RET(upload_vec(&tmp, &be, std::vector<float>(beta_host, beta_host + 256), 256));
+  const int max_chunks = (HW + GN_ROWS_PER_CHUNK - 1) / GN_ROWS_PER_CHUNK;
+  RET(tmp.dalloc((void**)&partial, (size_t)B * max_chunks * 32 * 3 * 4));
+  RET(tmp.dalloc((void**)&stats, (size_t)B * 32 * sizeof(float2)));
+  KCHK(launch_groupnorm(c->dt, buf, rsd, B, HW, 256, ga, be, 1e-5f, relu, partial, stats, c->stream), "group_norm");
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_export_nchw(c->dt, buf, y + (size_t)b * 256 * HW, 256, HW, b * HW, 256, c->stream), "export");
+  return 0;
+}
+
+int64_t sylph_device_bytes(sylph_ctx* c) { return c->bytes; }
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+"""Thin Python handle over one libsylph_hip context (one per process / GPU).
+
+Tensors are torch CUDA(ROCm) tensors used purely as device-memory owners: every stage below is one
+call through the C ABI (include/sylph_hip.h) into hand-written HIP kernels.
+"""
+import ctypes
+from ctypes import c_int, c_int64, c_void_p
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import SylphConfig, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _iarr(v: Sequence[int]):
+    return (c_int * len(v))(*[int(x) for x in v])
+
+
+def config_from_cfg(cfg) -> SylphConfig:
+    """Map the yacs node (sylph_amd.config / the reference's keys) onto the C config struct."""
+    L = _lib.lib()
+    sc = SylphConfig()
+    L.sylph_config_default(ctypes.byref(sc))
+    if cfg is None:
+        return sc
+    m = cfg.MODEL
+    f = m.FCOS
+    sc.resnet_depth = int(m.RESNETS.DEPTH)
+    sc.stride_in_1x1 = int(bool(m.RESNETS.get("STRIDE_IN_1X1", True)))
+    sc.num_cls_convs = int(f.NUM_CLS_CONVS)
+    sc.num_box_convs = int(f.NUM_BOX_CONVS)
+    if int(f.NUM_SHARE_CONVS) != 0:
+        raise NotImplementedError("MODEL.FCOS.NUM_SHARE_CONVS != 0 is not supported")
+    if bool(f.USE_DEFORMABLE):
+        raise NotImplementedError("MODEL.FCOS.USE_DEFORMABLE is not supported")
+    if str(f.NORM) != "GN":
+        raise NotImplementedError("MODEL.FCOS.NORM must be 'GN'")
+    strides = list(f.FPN_STRIDES)
+    sc.nlevels = len(strides)
+    for i, s in enumerate(strides):
+        sc.strides[i] = int(s)
+    for i in range(3):
+        sc.pixel_mean[i] = float(m.PIXEL_MEAN[i])
+        sc.pixel_std[i] = float(m.PIXEL_STD[i])
+    sc.use_scale = int(bool(f.USE_SCALE))
+    sc.pre_nms_thresh = float(f.INFERENCE_TH_TEST)
+    sc.pre_nms_topk = int(f.PRE_NMS_TOPK_TEST)
+    sc.nms_thresh = float(f.NMS_TH)
+    sc.post_nms_topk = int(f.POST_NMS_TOPK_TEST)
+    sc.thresh_with_ctr = int(bool(f.THRESH_WITH_CTR))
+    bq = sorted(list(f.BOX_QUALITY))
+    if bq == ["ctrness"]:
+        sc.quality_mode = 0
+    elif bq == ["iou"]:
+        sc.quality_mode = 1
+    elif bq == ["ctrness", "iou"]:
+        sc.quality_mode = 2
+    else:
+        raise NotImplementedError(f"MODEL.FCOS.BOX_QUALITY {bq}")
+    sc.prior_prob = float(f.PRIOR_PROB)
+    cg = m.META_LEARN.CODE_GENERATOR
+    sc.cond_use_bias = int(bool(cg.USE_BIAS))
+    tl = list(cg.TOWER_LAYERS)
+    for layer in tl:
+        if list(layer) != ["GN", "ReLU"]:
+            raise NotImplementedError(f"CODE_GENERATOR.TOWER_LAYERS entry {layer} (only ['GN','ReLU'])")
+    sc.cg_tower_layers = len(tl)
+    cl = list(cg.CLS_LAYER)
+    if len(cl) != 3 or cl[0] not in ("", "none") or cl[1] != "" or int(cl[2]) != 1:
+        raise NotImplementedError(f"CODE_GENERATOR.CLS_LAYER {cl} (only ['', '', 1])")
+    bl = list(cg.BIAS_LAYER)
+    sc.cg_has_bias = int(len(bl) != 0)
+    if len(cg.WEIGHT_LAYER) or len(cg.SCALE_LAYER):
+        raise NotImplementedError("CODE_GENERATOR.WEIGHT_LAYER / SCALE_LAYER are not supported")
+    if bool(cg.COMPRESS_CODE_W_MAX) or bool(cg.CLS_REWEIGHT) or bool(cg.BOX_ON):
+        raise NotImplementedError("COMPRESS_CODE_W_MAX / CLS_REWEIGHT / BOX_ON are not supported")
+    sc.cg_bias_l2_norm = int(bool(cg.BIAS_L2_NORM))
+    sc.cg_post_norm = int(str(cg.POST_NORM) != "")
+    if sc.cg_post_norm and str(cg.POST_NORM) != "GN":
+        raise NotImplementedError("CODE_GENERATOR.POST_NORM must be '' or 'GN'")
+    sc.cg_conv_l2_norm = int(bool(cg.CONV_L2_NORM))
+    sc.cg_use_weight_scale = int(bool(cg.USE_WEIGHT_SCALE))
+    return sc
+
+
+class Engine:
+    """One HIP context: weights + per-batch-shape workspaces, all on ``device``."""
+
+    def __init__(self, cfg=None, dtype: str = "bf16", device: int = 0, cand_cap: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sylph_amd.Engine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.L = _lib.lib()
+        self.device = torch.device("cuda", device)
+        self.dtype = dtype
+        self._ctx = c_void_p(0)
+        dt = {"bf16": _lib.SYLPH_BF16, "f32": _lib.SYLPH_F32, "fp32": _lib.SYLPH_F32}[dtype]
+        check(self.L.sylph_ctx_create(device, dt, ctypes.byref(self._ctx)), "ctx_create")
+        self.sc = config_from_cfg(cfg)
+        if cand_cap:
+            self.sc.cand_cap = cand_cap
+        check(self.L.sylph_set_config(self._ctx, ctypes.byref(self.sc)), "set_config")
+        self.nlevels = self.sc.nlevels
+        self._batch = None  # (B, H, W, [(h,w)...])
+        self._ncls = 0
+        self._keep = []  # tensors that must outlive queued kernels
+
+    def close(self):
+        if self._ctx:
+            self.L.sylph_ctx_destroy(self._ctx)
+            self._ctx = c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        check(self.L.sylph_set_stream(self._ctx, c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # ---- weights ------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Reference checkpoint keys -> packed device weights."""
+        for k, v in sd.items():
+            if not torch.is_tensor(v) or not v.is_floating_point():
+                continue
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (c_int64 * max(t.dim(), 1))(*(list(t.shape) if t.dim() else [1]))
+            check(self.L.sylph_load_weight(self._ctx, k.encode(), c_void_p(t.data_ptr()), shape, max(t.dim(), 1)),
+                  f"load_weight({k})")
+        check(self.L.sylph_finalize_weights(self._ctx), "finalize_weights")
+
+    # ---- query / support image path ----------------------------------------------------------------
+    def level_shapes(self, H: int, W: int) -> List[Tuple[int, int]]:
+        h, w = H // 8, W // 8
+        out = []
+        for _ in range(self.nlevels):
+            out.append((h, w))
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return out
+
+    def preprocess(self, images: List[torch.Tensor]) -> Tuple[int, int]:
+        self._stream()
+        imgs = [im.to(self.device, torch.float32).contiguous() for im in images]
+        B = len(imgs)
+        ptrs = (c_void_p * B)(*[im.data_ptr() for im in imgs])
+        hs, ws = _iarr([im.shape[1] for im in imgs]), _iarr([im.shape[2] for im in imgs])
+        ph, pw = c_int(0), c_int(0)
+        check(self.L.sylph_preprocess(self._ctx, B, ptrs, hs, ws, ctypes.byref(ph), ctypes.byref(pw)), "preprocess")
+        self._keep = imgs
+        self._batch = (B, ph.value, pw.value, [(int(im.shape[1]), int(im.shape[2])) for im in imgs])
+        return ph.value, pw.value
+
+    def backbone(self):
+        self._stream()
+        check(self.L.sylph_backbone_fpn(self._ctx), "backbone_fpn")
+
+    def import_pyramid(self, levels: List[torch.Tensor], padded_hw: Tuple[int, int],
+                       image_sizes: Optional[List[Tuple[int, int]]] = None):
+        self._stream()
+        B = levels[0].shape[0]
+        H, W = padded_hw
+        lv = [t.to(self.device, torch.float32).contiguous() for t in levels]
+        exp = self.level_shapes(H, W)
+        for t, (h, w) in zip(lv, exp):
+            assert tuple(t.shape) == (B, 256, h, w), f"level shape {tuple(t.shape)} != {(B, 256, h, w)}"
+        sizes = image_sizes or [(H, W)] * B
+        ptrs = (c_void_p * len(lv))(*[t.data_ptr() for t in lv])
+        check(self.L.sylph_import_pyramid(self._ctx, B, H, W, _iarr([s[0] for s in sizes]),
+                                          _iarr([s[1] for s in sizes]), ptrs), "import_pyramid")
+        self._keep = lv
+        self._batch = (B, H, W, list(sizes))
+
+    def export_pyramid(self) -> List[torch.Tensor]:
+        self._stream()
+        B, H, W, _ = self._batch
+        out = []
+        for l, (h, w) in enumerate(self.level_shapes(H, W)):
+            t = torch.empty(B, 256, h, w, device=self.device, dtype=torch.float32)
+            check(self.L.sylph_export_pyramid(self._ctx, l, _ptr(t)), "export_pyramid")
+            out.append(t)
+        return out
+
+    def head(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor]):
+        self._stream()
+        assert cls_conv.dim() == 4, f"Weight has dimension: {cls_conv.dim()}"
+        assert cls_conv.size(1) == 256 and cls_conv.size(2) == 1 and cls_conv.size(3) == 1
+        w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256).contiguous()
+        b = cls_bias.to(self.device, torch.float32).reshape(-1).contiguous() if cls_bias is not None else None
+        if b is not None:
+            assert b.numel() == w.size(0)
+        self._codes = (w, b)
+        self._ncls = w.size(0)
+        check(self.L.sylph_fcos_head(self._ctx, _ptr(w), _ptr(b), self._ncls), "fcos_head")
+
+    def export_head(self):
+        self._stream()
+        B, H, W, _ = self._batch
+        lo, rg, ct, io = [], [], [], []
+        for l, (h, w) in enumerate(self.level_shapes(H, W)):
+            a = torch.empty(B, self._ncls, h, w, device=self.device)
+            r = torch.empty(B, 4, h, w, device=self.device)
+            c = torch.empty(B, 1, h, w, device=self.device)
+            q = torch.empty(B, 1, h, w, device=self.device)
+            check(self.L.sylph_export_head(self._ctx, l, _ptr(a), _ptr(r), _ptr(c), _ptr(q)), "export_head")
+            lo.append(a); rg.append(r); ct.append(c); io.append(q)
+        return lo, rg, ct, io
+
+    def decode(self, out_sizes: Optional[List[Tuple[int, int]]] = None, max_out: Optional[int] = None):
+        """-> per image dict of device tensors (pred_boxes, scores, pred_classes, fpn_levels, locations,
+        cand_index).  One device->host copy of the per-image counts (the only sync of a query step)."""
+        self._stream()
+        B = self._batch[0]
+        K = int(self.sc.post_nms_topk)
+        if max_out is None:
+            max_out = 2 * K if K > 0 else int(self.sc.pre_nms_topk) * self.nlevels
+        dev = self.device
+        boxes = torch.empty(B, max_out, 4, device=dev)
+        scores = torch.empty(B, max_out, device=dev)
+        classes = torch.empty(B, max_out, device=dev, dtype=torch.int32)
+        levels = torch.empty(B, max_out, device=dev, dtype=torch.int32)
+        locs = torch.empty(B, max_out, 2, device=dev)
+        cand = torch.empty(B, max_out, device=dev, dtype=torch.int32)
+        counts = torch.empty(B + 1, device=dev, dtype=torch.int32)  # [B] = status word
+        oh = _iarr([s[0] for s in out_sizes]) if out_sizes is not None else None
+        ow = _iarr([s[1] for s in out_sizes]) if out_sizes is not None else None
+        check(self.L.sylph_decode_nms(self._ctx, oh, ow, max_out, _ptr(boxes), _ptr(scores), _ptr(classes),
+                                      _ptr(levels), _ptr(locs), _ptr(cand), _ptr(counts),
+                                      c_void_p(counts.data_ptr() + 4 * B)), "decode_nms")
+        cnt = counts.cpu().tolist()
+        status = cnt[B]
+        if status & 1:
+            raise RuntimeError("sylph decode: per-level candidate capacity exceeded (raise cand_cap)")
+        if status & 2:
+            raise RuntimeError("sylph decode: more tied detections than max_out")
+        res = []
+        for i in range(B):
+            n = cnt[i]
+            res.append({"pred_boxes": boxes[i, :n], "scores": scores[i, :n], "pred_classes": classes[i, :n].long(),
+                        "fpn_levels": levels[i, :n].long(), "locations": locs[i, :n], "cand_index": cand[i, :n].long()})
+        return res
+
+    # ---- support path -------------------------------------------------------------------------------
+    def codegen(self, boxes: torch.Tensor) -> torch.Tensor:
+        self._stream()
+        B = self._batch[0]
+        bx = boxes.to(self.device, torch.float32).reshape(-1, 4).contiguous()
+        assert bx.shape[0] == B, f"pooled_features.shape[0] {bx.shape[0]} Vs batch_size * num_shots {B}"
+        out = torch.empty(257, device=self.device)
+        self._keep_boxes = bx
+        check(self.L.sylph_codegen(self._ctx, _ptr(bx), _ptr(out)), "codegen")
+        return out
+
+    def normalize_codes(self, codes: torch.Tensor) -> torch.Tensor:
+        self._stream()
+        assert codes.is_cuda and codes.dtype == torch.float32 and codes.is_contiguous() and codes.shape[-1] == 257
+        check(self.L.sylph_normalize_codes(self._ctx, _ptr(codes), codes.shape[0]), "normalize_codes")
+        return codes
+
+    # ---- primitive entries (kernel parity tests) ------------------------------------------------------
+    def conv2d(self, x, w, scale=None, shift=None, stride=1, pad=0, relu=False, residual=None):
+        self._stream()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, C, H, W = x.shape
+        wh = w.detach().cpu().float().contiguous()
+        Cout, _, KH, KW = wh.shape
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        y = torch.empty(B, Cout, Ho, Wo, device=self.device)
+        sc = scale.detach().cpu().float().contiguous() if scale is not None else None
+        sh = shift.detach().cpu().float().contiguous() if shift is not None else None
+        rs = residual.to(self.device, torch.float32).contiguous() if residual is not None else None
+        check(self.L.sylph_conv2d(self._ctx, _ptr(x), B, C, H, W, _ptr(wh), Cout, KH, KW, stride, pad, _ptr(sc),
+                                  _ptr(sh), int(relu), _ptr(rs), _ptr(y)), "conv2d")
+        return y
+
+    def group_norm(self, x, gamma, beta, relu=False):
+        self._stream()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, C, H, W = x.shape
+        assert C == 256
+        y = torch.empty_like(x)
+        g, b = gamma.detach().cpu().float().contiguous(), beta.detach().cpu().float().contiguous()
+        check(self.L.sylph_group_norm(self._ctx, _ptr(x), B, H, W, _ptr(g), _ptr(b), int(relu), _ptr(y)), "group_norm")
+        return y
+
+    def device_bytes(self) -> int:
+        return int(self.L.sylph_device_bytes(self._ctx))

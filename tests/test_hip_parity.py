@@ -1,0 +1,312 @@
+"""GPU parity tests: the HIP path (through the C ABI) against torch fp32 references of single ops,
+against the golden vectors generated from the reference, and against the CPU oracle end to end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(dtype, cfg=None, **kw):
+    from sylph_amd.engine import Engine
+    return Engine(cfg, dtype=dtype, **kw)
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _cfg(lvis=False, **over):
+    from sylph_amd.config import get_default_cfg
+    cfg = get_default_cfg()
+    cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+    cfg.MODEL.META_LEARN.EPISODIC_LEARNING = True
+    cg.CONV_L2_NORM = True
+    cg.TOWER_LAYERS = [["GN", "ReLU"], ["GN", "ReLU"]]
+    cg.CLS_LAYER = ["", "", 1]
+    cg.BIAS_LAYER = ["", "", 1]
+    if lvis:
+        cg.BIAS_L2_NORM = True
+        cfg.MODEL.FCOS.POST_NMS_TOPK_TEST = 300
+    for k, v in over.items():
+        cfg.merge_from_list([k, v])
+    return cfg
+
+
+CONV_CASES = [
+    # C, Cout, k, stride, pad, H, W, B, relu, residual
+    (64, 64, 1, 1, 0, 20, 24, 2, True, False),
+    (64, 256, 1, 1, 0, 17, 13, 1, False, True),
+    (256, 128, 1, 2, 0, 18, 22, 2, True, False),
+    (128, 128, 3, 1, 1, 15, 19, 2, True, False),
+    (256, 256, 3, 1, 1, 13, 21, 1, False, False),
+    (256, 256, 3, 2, 1, 13, 21, 2, False, False),
+    (256, 6, 3, 1, 1, 9, 11, 2, False, False),
+    (256, 20, 1, 1, 0, 16, 20, 2, False, False),
+    (512, 1024, 1, 1, 0, 8, 10, 1, True, True),
+    (256, 256, 3, 1, 1, 7, 7, 5, True, False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(dtype, case):
+    C, Cout, k, stride, pad, H, W, B, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Cout, C, k, k, generator=g) / (C * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    eng = _engine(dtype)
+    y = eng.conv2d(x, w, scale, shift, stride, pad, relu, res).cpu()
+    if dtype == "bf16":
+        x, w = _bf16_round(x), _bf16_round(w)
+        res = _bf16_round(res) if res is not None else None
+    ref = F.conv2d(x, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    err = (y - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 7, 7), (1, 33, 41), (3, 100, 21)])
+def test_group_norm_matches_torch(dtype, shape):
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, 256, H, W, generator=g) * 2.0 + 0.7
+    gamma = 1 + 0.1 * torch.randn(256, generator=g)
+    beta = 0.1 * torch.randn(256, generator=g)
+    eng = _engine(dtype)
+    y = eng.group_norm(x, gamma, beta, relu=True).cpu()
+    xr = _bf16_round(x) if dtype == "bf16" else x
+    ref = F.relu(F.group_norm(xr, 32, gamma, beta, eps=1e-5))
+    tol = 1e-5 if dtype == "f32" else 2e-2
+    assert (y - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+# --------------------------------------------------------------------------------- goldens (reference)
+def _feats(g, prefix="feat"):
+    return [torch.from_numpy(g[f"{prefix}{l}_q8"].astype(np.float32) / 32.0) for l in range(5)]
+
+
+@pytest.fixture(scope="module")
+def g1(golden_dir):
+    return np.load(os.path.join(golden_dir, "g1_head_decode.npz"))
+
+
+@pytest.fixture(scope="module")
+def g3(golden_dir):
+    return np.load(os.path.join(golden_dir, "g3_codegen.npz"))
+
+
+@pytest.fixture(scope="module")
+def head_engine():
+    from oracle import weights as W
+    eng = _engine("f32", _cfg())
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    return eng
+
+
+@pytest.mark.parametrize("tag", ["n1_t50", "n5_t50", "n20_t50"])
+def test_head_matches_reference_golden(g1, head_engine, tag):
+    eng = head_engine
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.head(torch.from_numpy(g1[f"{tag}_cls_conv"]), torch.from_numpy(g1[f"{tag}_cls_bias"]))
+    lo, rg, ct, io = eng.export_head()
+    for l in range(5):
+        np.testing.assert_allclose(lo[l].cpu().numpy(), g1[f"{tag}_logits{l}"], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(rg[l].cpu().numpy(), g1[f"reg{l}"], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(ct[l].cpu().numpy(), g1[f"ctr{l}"], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(io[l].cpu().numpy(), g1[f"iou{l}"], atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("tag,thr", [("n1_t50", 0.05), ("n5_t50", 0.05), ("n20_t50", 0.05), ("n20_t11", 0.011)])
+def test_decode_matches_reference_golden(g1, tag, thr):
+    """boxes/scores within 1e-3 and identical kept (level, location, class) triples."""
+    from oracle import weights as W
+    eng = _engine("f32", _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": thr}))
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.head(torch.from_numpy(g1[f"{tag}_cls_conv"]), torch.from_numpy(g1[f"{tag}_cls_bias"]))
+    dets = eng.decode()
+    for i, d in enumerate(dets):
+        pre = f"{tag}_img{i}"
+        assert d["scores"].numel() == int(g1[f"{tag}_count"][i])
+        np.testing.assert_array_equal(d["pred_classes"].cpu().numpy(), g1[f"{pre}_pred_classes"])
+        np.testing.assert_array_equal(d["fpn_levels"].cpu().numpy(), g1[f"{pre}_fpn_levels"])
+        np.testing.assert_array_equal(d["locations"].cpu().numpy(), g1[f"{pre}_locations"])
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), g1[f"{pre}_scores"], atol=1e-3)
+        np.testing.assert_allclose(d["pred_boxes"].cpu().numpy(), g1[f"{pre}_pred_boxes"], atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("lvis", [False, True])
+@pytest.mark.parametrize("S", [1, 2, 5])
+def test_codegen_matches_reference_golden(g3, lvis, S):
+    from oracle import weights as W
+    eng = _engine("f32", _cfg(lvis))
+    eng.load_state_dict(W.codegen_state_dict(seed=2))
+    eng.import_pyramid(_feats(g3, f"s{S}_feat"), (192, 256))
+    code = eng.codegen(torch.from_numpy(g3[f"s{S}_boxes"])).cpu().numpy()
+    tag = f"{'lvis' if lvis else 'coco'}_s{S}"
+    np.testing.assert_allclose(code[:256], g3[f"{tag}_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(code[256], g3[f"{tag}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("tagc", ["coco", "lvis"])
+def test_normalize_matches_reference_golden(g3, tagc):
+    from oracle import weights as W
+    eng = _engine("f32", _cfg(tagc == "lvis"))
+    eng.load_state_dict(W.codegen_state_dict(seed=2))
+    codes = torch.stack([torch.cat([torch.from_numpy(g3[f"{tagc}_s{S}_cls_conv"]).reshape(-1),
+                                    torch.from_numpy(g3[f"{tagc}_s{S}_cls_bias"]).reshape(-1)]) for S in (1, 2, 5)])
+    out = eng.normalize_codes(codes.cuda().contiguous()).cpu().numpy()
+    for i in range(3):
+        np.testing.assert_allclose(out[i, :256], g3[f"{tagc}_norm{i}_cls_conv"].reshape(-1), atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(out[i, 256], g3[f"{tagc}_norm{i}_cls_bias"].reshape(-1)[0], atol=1e-5, rtol=1e-4)
+
+
+# --------------------------------------------------------------------------------- oracle, end to end
+@pytest.fixture(scope="module")
+def full_sd():
+    from oracle import weights as W
+    return W.synthetic_state_dict(0, depth=50)
+
+
+def test_backbone_fpn_matches_oracle_f32(full_sd):
+    from oracle import backbone as OB, weights as W
+    imgs = W.synthetic_images(2, 120, 150, seed=5)
+    imgs[1] = imgs[1][:, :97, :131].contiguous()
+    eng = _engine("f32", _cfg())
+    eng.load_state_dict(full_sd)
+    H, Wd = eng.preprocess(imgs)
+    assert (H, Wd) == (128, 160)
+    eng.backbone()
+    got = eng.export_pyramid()
+    x, _ = OB.preprocess(imgs)
+    ref = OB.backbone_fpn(x, full_sd, 50)
+    for l in range(5):
+        r = ref[l]
+        err = (got[l].cpu() - r).abs().max().item()
+        assert err <= 1e-3 * max(1.0, r.abs().max().item()), f"level {l}: {err}"
+
+
+def test_backbone_fpn_bf16_close_to_oracle(full_sd):
+    from oracle import backbone as OB, weights as W
+    imgs = W.synthetic_images(1, 128, 160, seed=6)
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(full_sd)
+    eng.preprocess(imgs)
+    eng.backbone()
+    got = eng.export_pyramid()
+    x, _ = OB.preprocess(imgs)
+    ref = OB.backbone_fpn(x, full_sd, 50)
+    for l in range(5):
+        a, b = got[l].cpu().flatten(), ref[l].flatten()
+        cos = F.cosine_similarity(a, b, dim=0).item()
+        assert cos > 0.995, f"level {l}: cosine {cos}"
+
+
+def _episode_codes(eng, sd, n_cls, shots, h, w, oracle_too=True):
+    from oracle import weights as W, episode as E, codegen as CG
+    codes_gpu, codes_ref = [], []
+    for c in range(n_cls):
+        sup = W.synthetic_images(shots, h, w, seed=50 + c)
+        boxes = W.synthetic_boxes(shots, h, w, seed=70 + c)
+        eng.preprocess(sup)
+        eng.backbone()
+        codes_gpu.append(eng.codegen(boxes))
+        if oracle_too:
+            codes_ref.append(E.forward_class_code(sup, boxes, sd))
+    g = eng.normalize_codes(torch.stack(codes_gpu).contiguous())
+    ref = None
+    if oracle_too:
+        recs = [{"support_set_target": torch.tensor(i), "class_name": str(i), "class_code": c}
+                for i, c in enumerate(codes_ref)]
+        ref = E.format_class_codes_shared(CG.forward_normalize_code(recs, sd))
+    return g, ref
+
+
+def test_full_episode_matches_oracle_f32(full_sd):
+    """C1-shaped episode (5-way 1-shot, 2 queries) at small size: codes, boxes, scores <= 1e-3 and the
+    same kept (level, location, class) candidates."""
+    from oracle import weights as W, episode as E
+    eng = _engine("f32", _cfg())
+    eng.load_state_dict(full_sd)
+    g, ref = _episode_codes(eng, full_sd, 5, 1, 128, 160)
+    np.testing.assert_allclose(g[:, :256].cpu().numpy(), ref["cls_conv"].reshape(5, 256).numpy(), atol=1e-3)
+    np.testing.assert_allclose(g[:, 256].cpu().numpy(), ref["cls_bias"].numpy(), atol=1e-3)
+    # make the synthetic detector fire: scale the codes, same scale on both sides
+    scale = 3.0
+    q = W.synthetic_images(2, 128, 160, seed=9)
+    codes_ref = {"cls_conv": ref["cls_conv"] * scale, "cls_bias": ref["cls_bias"]}
+    want = E.forward_instances(q, codes_ref, full_sd)
+    eng.preprocess(q)
+    eng.backbone()
+    eng.head(ref["cls_conv"] * scale, ref["cls_bias"])  # identical codes -> isolates the query path
+    got = eng.decode()
+    assert sum(w["scores"].numel() for w in want) > 20
+    for wv, gv in zip(want, got):
+        assert gv["scores"].numel() == wv["scores"].numel()
+        np.testing.assert_array_equal(gv["cand_index"].cpu().numpy(), _cand_ordinals(wv, 128, 160, 5))
+        np.testing.assert_allclose(gv["scores"].cpu().numpy(), wv["scores"].numpy(), atol=1e-3)
+        np.testing.assert_allclose(gv["pred_boxes"].cpu().numpy(), wv["pred_boxes"].numpy(), atol=2e-2, rtol=1e-3)
+        np.testing.assert_array_equal(gv["pred_classes"].cpu().numpy(), wv["pred_classes"].numpy())
+
+
+def _cand_ordinals(inst, H, W, N):
+    """(level, location, class) ordinal used by the HIP path, from oracle fields."""
+    base, bases = 0, []
+    h, w = H // 8, W // 8
+    for _ in range(5):
+        bases.append(base)
+        base += h * w
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    lv = inst["fpn_levels"].numpy()
+    return (np.asarray(bases)[lv] + inst["loc_index"].numpy()) * N + inst["pred_classes"].numpy()
+
+
+def test_full_size_properties_bf16(full_sd):
+    """BASELINE config C2 shape (800x1333 -> 800x1344, 5-way): size-independent properties."""
+    from oracle import weights as W
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(full_sd)
+    q = W.synthetic_images(2, 800, 1333, seed=3)
+    codes = W.synthetic_codes(5, seed=4, scale=3.0)
+    assert eng.preprocess(q) == (800, 1344)
+    eng.backbone()
+    pyr = eng.export_pyramid()
+    assert [tuple(p.shape[2:]) for p in pyr] == [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    assert all(torch.isfinite(p).all() for p in pyr)
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    d1 = eng.decode()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    d2 = eng.decode()
+    for a, b in zip(d1, d2):  # determinism
+        assert torch.equal(a["cand_index"], b["cand_index"]) and torch.equal(a["scores"], b["scores"])
+    for d in d1:
+        s = d["scores"]
+        assert s.numel() > 0 and torch.isfinite(s).all() and (s[:-1] >= s[1:]).all()
+        bx = d["pred_boxes"]
+        assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= 1333).all() and (bx[:, 1] >= 0).all() and (bx[:, 3] <= 800).all()
+        assert ((bx[:, 2] - bx[:, 0]) > 0).all() and ((bx[:, 3] - bx[:, 1]) > 0).all()
+        # NMS invariant: no same-class pair above the IoU threshold (checked on unclipped geometry is
+        # stricter than needed; clipped boxes only shrink intersections proportionally) -> use 0.6 + slack
+        bxc, cl = bx.cpu(), d["pred_classes"].cpu()
+        area = (bxc[:, 2] - bxc[:, 0]) * (bxc[:, 3] - bxc[:, 1])
+        lt = torch.max(bxc[:, None, :2], bxc[None, :, :2])
+        rb = torch.min(bxc[:, None, 2:], bxc[None, :, 2:])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        iou = inter / (area[:, None] + area[None, :] - inter)
+        same = (cl[:, None] == cl[None, :]) & ~torch.eye(len(cl), dtype=torch.bool)
+        assert (iou[same] <= 0.75).all()
