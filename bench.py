@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- query images/sec of the Sylph MetaOneStageDetector inference path on MI355X.
+
+Workload = BASELINE.json configs[1]: R-50-FPN, 5-way 5-shot, 800x1333 synthetic queries, bf16.
+One "step" = one pass of the hot path over one batch of B query images already resident in HBM:
+normalise+pad -> ResNet-50-FPN -> FCOS towers + class-conditional classifier -> decode + NMS +
+postprocess (device outputs; one 4*(B+1)-byte count read-back per step).  The episode set-up (support
+images -> class codes -> RCCL all-gather -> normalise) runs once before the timed region and is
+reported separately (it is amortised over all queries of an episode).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the MFMA
+implicit-GEMM conv kernel, timed with HIP events on its launch stream inside the timed region) and
+`cpu_baseline` (the CPU oracle = fp32 torch restatement of the reference, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sylph-few-shot-detection_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per 800x1333 (padded 800x1344) query image, R-50-FPN, N = 5
+GFLOP_PER_IMAGE_TOTAL = 411.45
+GFLOP_PER_IMAGE_STEM = 5.06          # direct-conv stem kernel, not part of the MFMA conv kernel
+GFLOP_PER_IMAGE_MFMA_CONV = GFLOP_PER_IMAGE_TOTAL - GFLOP_PER_IMAGE_STEM
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def make_cfg():
+    from sylph_amd.config import get_default_cfg
+    cfg = get_default_cfg()
+    cfg.MODEL.META_LEARN.EPISODIC_LEARNING = True
+    cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+    cg.CONV_L2_NORM = True
+    cg.TOWER_LAYERS = [["GN", "ReLU"], ["GN", "ReLU"]]
+    cg.CLS_LAYER = ["", "", 1]
+    cg.BIAS_LAYER = ["", "", 1]
+    cfg.MODEL.META_LEARN.EVAL_SHOT = 5
+    cfg.MODEL.META_LEARN.CLASS = 5
+    return cfg
+
+
+def dev_images(n, h, w, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return [torch.randint(0, 256, (3, h, w), generator=g, device=device).float() for _ in range(n)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="query images per GPU per step")
+    ap.add_argument("--ways", type=int, default=5)
+    ap.add_argument("--shots", type=int, default=5)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--code-scale", type=float, default=3.0,
+                    help="multiplier on the normalised class codes so the random-weight detector fires (SURVEY 8d)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from oracle import weights as W  # synthetic weights/inputs only (no model arithmetic)
+    from sylph_amd import distributed as D
+    from sylph_amd.engine import Engine
+
+    cfg = make_cfg()
+    sd = W.synthetic_state_dict(0, depth=50)
+    eng = Engine(cfg, dtype=args.dtype, device=local_rank)
+    eng.load_state_dict(sd)
+    H, Wd, B, N, S = args.height, args.width, args.batch, args.ways, args.shots
+
+    # ---- episode set-up: this rank's classes -> codes -> all-gather -> normalise (untimed) ----------
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c0, c1 = D.inference_shard(N, rank, world)
+    local = []
+    for c in range(c0, c1):
+        sup = dev_images(S, H, Wd, 1000 + c, device)
+        boxes = W.synthetic_boxes(S, H, Wd, seed=2000 + c)
+        eng.preprocess(sup)
+        eng.backbone()
+        local.append(eng.codegen(boxes))
+    if local:
+        lc = torch.stack(local)
+        packed = D.pack_codes(lc[:, :256], lc[:, 256], list(range(c0, c1)))
+    else:
+        packed = torch.zeros(0, D.ROW, device=device)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    rows = D.order_by_class_id(D.gather_packed_codes(packed), N)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    codes = eng.normalize_codes(rows[:, :257].contiguous())
+    cls_conv = (codes[:, :256] * args.code_scale).reshape(N, 256, 1, 1).contiguous()
+    cls_bias = codes[:, 256].contiguous()
+    torch.cuda.synchronize()
+    setup = {"codegen_s": t1 - t0, "allgather_s": t2 - t1, "support_images": (c1 - c0) * S}
+
+    # ---- query steps -----------------------------------------------------------------------------
+    queries = dev_images(B, H, Wd, 7 + rank, device)
+
+    def step():
+        eng.preprocess(queries)
+        eng.backbone()
+        eng.head(cls_conv, cls_bias)
+        return eng.decode()
+
+    for _ in range(args.warmup):
+        dets = step()
+    eng.profile_enable(True)
+    eng.profile_read()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        dets = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ndet = [int(d["scores"].numel()) for d in dets]
+
+    if rank == 0:
+        total_images = world * B * args.steps
+        value = total_images / elapsed
+        conv_s = prof["conv_ms"] / 1e3
+        launches = max(prof["conv_launches"], 1)
+        images_timed = B * args.steps
+        alg_flops = GFLOP_PER_IMAGE_MFMA_CONV * 1e9 * images_timed  # all conv launches of the region, this rank
+        achieved = alg_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        roofline = {
+            "kernel": "conv_igemm_kernel (implicit-GEMM MFMA conv, all launches of the timed region)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+            "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+            "traffic": None,
+            "launches": launches, "avg_launch_us": round(conv_s / launches * 1e6, 2),
+            "algorithmic_gflop_per_launch": round(alg_flops / launches / 1e9, 3),
+            "gflop_counted_by_library_per_image": round(prof["conv_flops"] / images_timed / 1e9, 2),
+            "conv_share_of_step_time": round(conv_s / elapsed, 3),
+        }
+        out = {
+            "metric": "query images/sec, R50-FPN 5-way 5-shot 800x1333 (whole job)", "value": round(value, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: R-50-FPN 5-way 5-shot, 800x1333 synthetic queries",
+                       "batch_per_gpu": B, "ways": N, "shots": S, "image": [H, Wd], "code_scale": args.code_scale,
+                       "parallelism": f"dp{world} (queries sharded, codes all-gathered once per episode)",
+                       "detections_last_step": ndet},
+            "images_per_sec_per_gpu": round(value / world, 2),
+            "tflops_sustained_per_gpu": round(GFLOP_PER_IMAGE_TOTAL * value / world / 1e3, 1),
+            "episode_setup": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in setup.items()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, queries, cls_conv, cls_bias, args.cpu_images)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd, queries, cls_conv, cls_bias, n_images):
+    """The CPU oracle (fp32 torch restatement of the reference path) on the host cores, batch 1,
+    first image excluded as warm-up (the reference protocol, meta_learn_evaluation.py:392-417)."""
+    from oracle import episode as E
+    import torch.nn.functional as F
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # pick the thread count that is actually fastest on this host (oversubscribed pods run the
+    # oracle ~50x slower at cpu_count() threads): time one tower-sized conv per candidate
+    x, w = torch.randn(1, 256, 100, 168), torch.randn(256, 256, 3, 3)
+    best, best_t = 1, float("inf")
+    for nt in sorted({t for t in (4, 8, 16, 32, 64, 128, avail) if t <= avail}):
+        torch.set_num_threads(nt)
+        F.conv2d(x, w, padding=1)
+        t0 = time.perf_counter()
+        F.conv2d(x, w, padding=1)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = nt, dt
+    torch.set_num_threads(best)
+    codes = {"cls_conv": cls_conv.cpu(), "cls_bias": cls_bias.cpu()}
+    imgs = [q.cpu() for q in queries[: n_images + 1]]
+    times = []
+    with torch.no_grad():
+        for i, im in enumerate(imgs):
+            t0 = time.perf_counter()
+            E.forward_instances([im], codes, sd)
+            dt = time.perf_counter() - t0
+            if i > 0 or len(imgs) == 1:
+                times.append(dt)
+    v = len(times) / sum(times)
+    return {"value": round(v, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} query image(s) 800x1333 through the fp32 CPU oracle (batch 1, 1 warm-up image)"}
+
+
+if __name__ == "__main__":
+    main()

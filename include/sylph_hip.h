@@ -128,6 +128,14 @@ int sylph_group_norm(sylph_ctx* ctx, const float* x_nchw_dev, int B, int H, int 
 /* Bytes of device memory currently held by the context (weights + workspace). */
 int64_t sylph_device_bytes(sylph_ctx* ctx);
 
+/* Measurement aid (no reference counterpart; the reference only logs wall-clock s/img,
+ * sylph/evaluation/meta_learn_evaluation.py:392-463): when enabled, every launch of the MFMA
+ * implicit-GEMM conv kernel is bracketed by HIP events on the launch stream.  sylph_profile_read
+ * synchronises the stream and returns the summed kernel time (ms), the algorithmic FLOPs
+ * (2*M*N*K of the logical problem) and the number of launches since the previous read. */
+int sylph_profile_enable(sylph_ctx* ctx, int on);
+int sylph_profile_read(sylph_ctx* ctx, double* conv_ms, double* conv_flops, int64_t* conv_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,9 +319,9 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
                   const float* logits, const float* pred, int pred_ld, const DecodeBuffers& buf,
                   const ImageOut* img_out_dev, float* out_boxes, float* out_scores, int* out_classes,
                   int* out_levels, float* out_locations, int* out_cand, int* out_counts, hipStream_t s) {
-  hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
-  hipMemsetAsync(buf.pool_count, 0, sizeof(unsigned) * B, s);
-  hipMemsetAsync(buf.status, 0, sizeof(int), s);
+  (void)hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
+  (void)hipMemsetAsync(buf.pool_count, 0, sizeof(unsigned) * B, s);
+  (void)hipMemsetAsync(buf.status, 0, sizeof(int), s);
   dim3 g1((max_nloc + SCAN_ROWS - 1) / SCAN_ROWS, nseg);
   hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
   hipLaunchKernelGGL(decode_select_kernel, dim3(nseg), dim3(1024), 0, s, cfg, segs_dev, buf);

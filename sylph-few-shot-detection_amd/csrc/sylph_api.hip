@@ -96,6 +96,11 @@ struct sylph_ctx {
   // plans
   std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
   Plan* cur = nullptr;
+  // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
+  bool prof = false;
+  struct ProfRec { hipEvent_t a, b; double flops; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
 
   int dalloc(void** p, size_t n) {
     if (n == 0) n = 16;
@@ -283,6 +288,25 @@ static int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geo
   return 0;
 }
 
+// launch the conv kernel, optionally bracketed by HIP events on the same stream
+static int timed_conv(sylph_ctx* c, DType dt, bool of32, const ConvArgs& a, int BM, int BN, double flops,
+                      hipStream_t s) {
+  if (!c->prof) return launch_conv(dt, of32, a, BM, BN, s);
+  sylph_ctx::ProfRec r;
+  if (!c->prof_free.empty()) {
+    r.a = c->prof_free.back().first; r.b = c->prof_free.back().second;
+    c->prof_free.pop_back();
+  } else {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -100;
+  }
+  r.flops = flops;
+  (void)hipEventRecord(r.a, s);
+  const int rc = launch_conv(dt, of32, a, BM, BN, s);
+  (void)hipEventRecord(r.b, s);
+  c->prof_recs.push_back(r);
+  return rc;
+}
+
 struct ConvOpts {
   int stride = 1, pad = 0;
   int relu_nch = 0, mul_nch = 0;
@@ -313,7 +337,8 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode; a.in_relu = o.in_relu;
   const DType dt = c->dt;
   const bool of32 = o.out_f32;
-  ops.push_back([a, BM, BN, dt, of32](hipStream_t s) { return launch_conv(dt, of32, a, BM, BN, s); });
+  const double flops = 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
+  ops.push_back([a, BM, BN, dt, of32, c, flops](hipStream_t s) { return timed_conv(c, dt, of32, a, BM, BN, flops, s); });
   return 0;
 }
 
@@ -677,13 +702,13 @@ int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out) {
 
 void sylph_ctx_destroy(sylph_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
   for (auto& kv : c->plans) {
-    if (kv.second->img_desc_host) hipHostFree(kv.second->img_desc_host);
-    if (kv.second->img_out_host) hipHostFree(kv.second->img_out_host);
+    if (kv.second->img_desc_host) (void)hipHostFree(kv.second->img_desc_host);
+    if (kv.second->img_out_host) (void)hipHostFree(kv.second->img_out_host);
   }
-  for (void* p : c->allocs) hipFree(p);
+  for (void* p : c->allocs) (void)hipFree(p);
   delete c;
 }
 
@@ -902,7 +927,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   a.n_ntiles = Npad / bn;
   a.Cin = 256; a.Cout = N; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
   a.in_ld = 256; a.out_ld = Npad;
-  KCHK(launch_conv(c->dt, true, a, BM, bn, c->stream), "cond_cls_logits");
+  KCHK(timed_conv(c, c->dt, true, a, BM, bn, 2.0 * (double)rows * N * 256.0, c->stream), "cond_cls_logits");
   return 0;
 }
 
@@ -983,7 +1008,7 @@ int sylph_conv2d(sylph_ctx* c, const float* x, int B, int C, int H, int W, const
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   sylph_ctx tmp;  // scratch allocations freed on return
   tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream;
-  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { hipStreamSynchronize(s); for (void* p : t->allocs) hipFree(p); } } guard{&tmp, c->stream};
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
   HostTensor hw;
   hw.shape = {Cout, C, KH, KW};
   hw.data.assign(w_host, w_host + (size_t)Cout * C * KH * KW);
@@ -1018,7 +1043,7 @@ int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const fl
   HIPCHK(hipSetDevice(c->device));
   sylph_ctx tmp;
   tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream;
-  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { hipStreamSynchronize(s); for (void* p : t->allocs) hipFree(p); } } guard{&tmp, c->stream};
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
   const int HW = H * W;
   void* buf;
   RET(tmp.dalloc(&buf, (size_t)B * HW * 256 * tmp.esz()));
@@ -1042,5 +1067,27 @@ int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const fl
 }
 
 int64_t sylph_device_bytes(sylph_ctx* c) { return c->bytes; }
+
+int sylph_profile_enable(sylph_ctx* c, int on) {
+  c->prof = on != 0;
+  return 0;
+}
+
+int sylph_profile_read(sylph_ctx* c, double* conv_ms, double* conv_flops, int64_t* conv_launches) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : c->prof_recs) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    fl += r.flops;
+    c->prof_free.push_back(std::make_pair(r.a, r.b));
+  }
+  if (conv_ms) *conv_ms = ms;
+  if (conv_flops) *conv_flops = fl;
+  if (conv_launches) *conv_launches = (int64_t)c->prof_recs.size();
+  c->prof_recs.clear();
+  return 0;
+}
 
 }  // extern "C"

@@ -291,3 +291,12 @@ class Engine:
 
     def device_bytes(self) -> int:
         return int(self.L.sylph_device_bytes(self._ctx))
+
+    def profile_enable(self, on: bool = True):
+        check(self.L.sylph_profile_enable(self._ctx, int(on)), "profile_enable")
+
+    def profile_read(self) -> Dict[str, float]:
+        """Summed conv-kernel time (HIP events on the launch stream), algorithmic FLOPs, launches."""
+        ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), c_int64(0)
+        check(self.L.sylph_profile_read(self._ctx, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_read")
+        return {"conv_ms": ms.value, "conv_flops": fl.value, "conv_launches": int(n.value)}
