@@ -191,37 +191,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- fused epilogue -------------------------------------------------------------------------
-  OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out);
-  const T* __restrict__ res = reinterpret_cast<const T*>(a.res);
+  // ---- fused epilogue ---------------------------------------------------------------------------
+  // accumulators -> LDS as fp32 [BM][BN] (aliases the staging buffers; the K loop ended on a
+  // barrier), then every lane owns 8 consecutive channels of one row: 16-byte residual loads and
+  // 16-byte (bf16) / 32-byte (fp32) stores, 256 B contiguous per 16 lanes.
+  static_assert(BM * BN * 4 <= 2 * (BM + BN) * 128, "epilogue tile does not fit the staging LDS");
+  float* const sC = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = nt * BN + wn * WTN + j * 32 + (lane & 31);
-    const bool nv = n < a.Cout;
-    const float sc = (nv && a.scale) ? a.scale[n] : 1.f;
-    const float sh = (nv && a.shift) ? a.shift[n] : 0.f;
-    const float mul = (n < a.mul_nch) ? sd.mul : 1.f;
-    const bool relu = n < a.relu_nch;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int pos = tile.y + row;
-        if (nv && pos < seg_rows) {
-          float v = acc[i][j][r] * sc + sh;
-          if (a.res_mode == 1) {
-            v += Cvt<T>::to_f(res[(size_t)(sd.res_row0 + pos) * a.res_ld + n]);
-          } else if (a.res_mode == 2) {
-            const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
-            const int rp = (oy >> 1) * sd.res_W + (ox >> 1);
-            v += Cvt<T>::to_f(res[(size_t)(sd.res_row0 + rp) * a.res_ld + n]);
-          }
-          v *= mul;
-          if (relu) v = v > 0.f ? v : 0.f;
-          out[(size_t)(sd.out_row0 + pos) * a.out_ld + n] = Cvt<OutT>::from_f(v);
-        }
+        const int col = wn * WTN + j * 32 + (lane & 31);
+        sC[row * BN + col] = acc[i][j][r];
       }
+  __syncthreads();
+
+  constexpr int TPR = BN / 8;     // lanes per output row
+  constexpr int RPP = 256 / TPR;  // rows per pass
+  OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out);
+  const T* __restrict__ res = reinterpret_cast<const T*>(a.res);
+  const int c8 = tid % TPR, rr = tid / TPR;
+  const int n0 = nt * BN + c8 * 8;
+  if (n0 >= a.Cout) return;
+  const bool vec = (n0 + 8 <= a.Cout) && ((a.out_ld & 7) == 0) && (a.res_mode == 0 || (a.res_ld & 7) == 0);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool nv = n0 + e < a.Cout;
+    sc[e] = (nv && a.scale) ? a.scale[n0 + e] : 1.f;
+    sh[e] = (nv && a.shift) ? a.shift[n0 + e] : 0.f;
+  }
+  for (int row = rr; row < BM; row += RPP) {
+    const int pos = tile.y + row;
+    if (pos >= seg_rows) break;
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(sC + row * BN + c8 * 8);
+      const float4 hi = *reinterpret_cast<const float4*>(sC + row * BN + c8 * 8 + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+    if (a.res_mode != 0) {
+      int rp = pos;
+      if (a.res_mode == 2) {
+        const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+        rp = (oy >> 1) * sd.res_W + (ox >> 1);
+      }
+      const T* rptr = res + (size_t)(sd.res_row0 + rp) * a.res_ld + n0;
+      if (vec) {
+        float rv[8];
+        load8<T>(rptr, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      } else {
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < a.Cout) v[e] += Cvt<T>::to_f(rptr[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (n0 + e < a.mul_nch) v[e] *= sd.mul;
+      if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    OutT* optr = out + (size_t)(sd.out_row0 + pos) * a.out_ld + n0;
+    if (vec) {
+      store8<OutT>(optr, v);
+    } else {
+      for (int e = 0; e < 8; ++e)
+        if (n0 + e < a.Cout) optr[e] = Cvt<OutT>::from_f(v[e]);
     }
   }
 }

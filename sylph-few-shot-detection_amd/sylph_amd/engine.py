@@ -239,11 +239,12 @@ class Engine:
             raise RuntimeError("sylph decode: per-level candidate capacity exceeded (raise cand_cap)")
         if status & 2:
             raise RuntimeError("sylph decode: more tied detections than max_out")
+        classes, levels, cand = classes.long(), levels.long(), cand.long()  # 3 launches, then views only
         res = []
         for i in range(B):
             n = cnt[i]
-            res.append({"pred_boxes": boxes[i, :n], "scores": scores[i, :n], "pred_classes": classes[i, :n].long(),
-                        "fpn_levels": levels[i, :n].long(), "locations": locs[i, :n], "cand_index": cand[i, :n].long()})
+            res.append({"pred_boxes": boxes[i, :n], "scores": scores[i, :n], "pred_classes": classes[i, :n],
+                        "fpn_levels": levels[i, :n], "locations": locs[i, :n], "cand_index": cand[i, :n]})
         return res
 
     # ---- support path -------------------------------------------------------------------------------

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd SQLite database (kernel-trace) into a per-kernel table:
+calls, total/avg/min/max duration.  Usage: python tools/rocpd_summary.py <results.db> [out.md]"""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("void ", "").replace("sylph::", "")
+    return name[:110]
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])
+        d = e - s
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f"| {k} | {a[0]} | {a[1] / 1e6:.3f} | {a[1] / a[0] / 1e3:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / total:.1f} |")
+    txt = "\n".join(lines)
+    print(txt)
+    if len(sys.argv) > 2:
+        with open(sys.argv[2], "w") as f:
+            f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
