@@ -32,8 +32,7 @@ import torch.distributed as dist  # noqa: E402
 
 # algorithmic work per 800x1333 (padded 800x1344) query image, R-50-FPN, N = 5
 GFLOP_PER_IMAGE_TOTAL = 411.45
-GFLOP_PER_IMAGE_STEM = 5.06          # direct-conv stem kernel, not part of the MFMA conv kernel
-GFLOP_PER_IMAGE_MFMA_CONV = GFLOP_PER_IMAGE_TOTAL - GFLOP_PER_IMAGE_STEM
+GFLOP_PER_IMAGE_MFMA_CONV = GFLOP_PER_IMAGE_TOTAL  # every conv of the path (stem included) runs on the MFMA kernel
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 

@@ -41,6 +41,8 @@ struct ConvArgs {
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
   int in_relu;                // apply ReLU to the input while staging (P7 = conv(relu(P6)))
+  int stem;                   // ResNet-stem A loader (see conv_igemm.hip)
+  int tap_dy;                 // input rows advanced per kernel-row tap (1; stem: rows per K-slice)
 };
 
 template <typename T> struct Cvt;

@@ -113,13 +113,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int pos = tile.y + r0 + 32 * i;
     const bool rv = pos < seg_rows;
     const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
-    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-    abase[i] = (sd.in_row0 + iy0 * sd.in_W + ix0) * a.in_ld + c16 * EPC;
     uint32_t m = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      const int kh = t / KW, kw = t - kh * KW;
-      const bool ok = rv && (unsigned)(iy0 + kh) < (unsigned)sd.in_H && (unsigned)(ix0 + kw) < (unsigned)sd.in_W;
-      m |= (ok ? 1u : 0u) << t;
+    if (a.stem) {
+      // ResNet stem (7x7 s2 p3 over a 4-channel-padded image): a K-slice is RPS kernel rows of an
+      // 8-pixel window [2*ox-4, 2*ox+4) x 4 channels (window pixel 0 and channel 3 carry zero
+      // weights), so every 16-byte chunk is PPC whole, aligned pixels of one input row.
+      constexpr int PPC = EPC / 4, CPR = 8 / PPC, RPS = 8 / CPR;
+      const int khl = c16 / CPR, pxo = (c16 % CPR) * PPC;
+      const int iy0 = oy * 2 - 3 + khl, ixw = ox * 2 - 4 + pxo;
+      abase[i] = (sd.in_row0 + iy0 * sd.in_W + ixw) * 4;
+      for (int t = 0; t < ntaps; ++t) {
+        const bool ok = rv && (unsigned)(iy0 + t * RPS) < (unsigned)sd.in_H && (t * RPS + khl) < 7 &&
+                        (unsigned)ixw < (unsigned)sd.in_W;
+        m |= (ok ? 1u : 0u) << t;
+      }
+    } else {
+      const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+      abase[i] = (sd.in_row0 + iy0 * sd.in_W + ix0) * a.in_ld + c16 * EPC;
+      for (int t = 0; t < ntaps; ++t) {
+        const int kh = t / KW, kw = t - kh * KW;
+        const bool ok = rv && (unsigned)(iy0 + kh) < (unsigned)sd.in_H && (unsigned)(ix0 + kw) < (unsigned)sd.in_W;
+        m |= (ok ? 1u : 0u) << t;
+      }
     }
     amask[i] = m;
   }
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   uint4 ra[AR], rb[BR];
   int tap = 0, cc = 0, kh = 0, kw = 0;  // state of the NEXT slice to fetch
   auto fetch = [&]() {
-    const int aoff = (kh * sd.in_W + kw) * a.in_ld + cc * BK;
+    const int aoff = (kh * a.tap_dy * sd.in_W + kw) * a.in_ld + cc * BK;
     const int boff = tap * Cin + cc * BK;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {

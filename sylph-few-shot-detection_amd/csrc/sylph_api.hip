@@ -78,8 +78,7 @@ struct sylph_ctx {
   std::vector<void*> allocs;
   std::map<std::string, HostTensor> host_w;
   // packed model
-  float* stem_w = nullptr;  // fp32 [7][7][3][64]
-  float *stem_scale = nullptr, *stem_shift = nullptr;
+  ConvLayer stem;  // 7x7 s2 stem packed for the implicit-GEMM stem loader
   struct Block { ConvLayer c1, c2, c3, sc; bool has_sc = false; };
   std::vector<std::vector<Block>> stages;  // res2..res5
   ConvLayer fpn_lat[3], fpn_out[3], p6, p7;  // index 0..2 = stage 3..5
@@ -315,6 +314,8 @@ struct ConvOpts {
   int in_relu = 0;
   bool out_f32 = false;
   int cout_override = -1;  // logical Cout (class-conditional conv)
+  int stem = 0;            // ResNet stem loader
+  double flops = -1.0;     // algorithmic FLOPs of the launch when they differ from 2*M*N*K (stem padding)
 };
 
 static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
@@ -335,9 +336,10 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.KH = L.KH; a.KW = L.KW; a.stride = o.stride; a.pad = o.pad;
   a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode; a.in_relu = o.in_relu;
+  a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
   const DType dt = c->dt;
   const bool of32 = o.out_f32;
-  const double flops = 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
+  const double flops = o.flops >= 0.0 ? o.flops : 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
   ops.push_back([a, BM, BN, dt, of32, c, flops](hipStream_t s) { return timed_conv(c, dt, of32, a, BM, BN, flops, s); });
   return 0;
 }
@@ -393,9 +395,10 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
   auto& ops = P->backbone_ops;
   const DType dt = c->dt;
   {
-    void *x0 = P->x0, *so = P->stem_out, *po = P->pool_out;
-    const float *sw = c->stem_w, *ss = c->stem_scale, *sh = c->stem_shift;
-    ops.push_back([=](hipStream_t s) { return launch_stem(dt, x0, sw, ss, sh, so, B, H, W, H2, W2, s); });
+    void *so = P->stem_out, *po = P->pool_out;
+    ConvOpts os; os.stem = 1; os.relu_nch = 1 << 30;
+    os.flops = 2.0 * (double)B * H2 * W2 * 64.0 * 147.0;
+    RET(add_conv(c, ops, c->stem, P->x0, 4, so, 64, image_segs(B, H, W, H2, W2), os));
     ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
   }
   const void* X = P->pool_out;
@@ -747,20 +750,29 @@ int sylph_finalize_weights(sylph_ctx* c) {
                      *rv = find_w(c, bu + ".stem.conv1.norm.running_var");
     if (!w || !g || !b || !rm || !rv) return fail("missing stem weights");
     if (w->shape[0] != 64 || w->shape[1] != 3 || w->shape[2] != 7 || w->shape[3] != 7) return fail("stem must be 64x3x7x7");
-    std::vector<float> pk(7 * 7 * 3 * 64);
-    for (int n = 0; n < 64; ++n)
-      for (int ci = 0; ci < 3; ++ci)
-        for (int kh = 0; kh < 7; ++kh)
-          for (int kw = 0; kw < 7; ++kw)
-            pk[((kh * 7 + kw) * 3 + ci) * 64 + n] = w->data[((n * 3 + ci) * 7 + kh) * 7 + kw];
-    RET(upload(c, (void**)&c->stem_w, pk.data(), pk.size() * 4));
-    std::vector<float> sc(64), sh(64);
-    for (int i = 0; i < 64; ++i) {
-      sc[i] = g->data[i] * (1.0f / sqrtf(rv->data[i] + 1e-5f));
-      sh[i] = b->data[i] - rm->data[i] * sc[i];
+    {
+      // Stem as an implicit GEMM (conv_igemm.hip, stem loader): K-slice s = RPS kernel rows of an
+      // 8-pixel x 4-channel window; window pixel 0, channel 3 and kernel rows >= 7 carry zeros.
+      const int BK = c->dt == DT_BF16 ? 64 : 32, RPS = BK / 32, NS = (7 + RPS - 1) / RPS;
+      HostTensor hs;
+      hs.shape = {64, BK, NS, 1};
+      hs.data.assign((size_t)64 * BK * NS, 0.f);
+      for (int n = 0; n < 64; ++n)
+        for (int s = 0; s < NS; ++s)
+          for (int e = 0; e < BK; ++e) {
+            const int kh = s * RPS + e / 32, px = (e % 32) / 4, ch = e % 4, kw = px - 1;
+            if (kh < 7 && kw >= 0 && kw < 7 && ch < 3)
+              hs.data[((size_t)n * BK + e) * NS + s] = w->data[((n * 3 + ch) * 7 + kh) * 7 + kw];
+          }
+      RET(pack_conv(c, {&hs}, &c->stem));
+      std::vector<float> sc(64), sh(64);
+      for (int i = 0; i < 64; ++i) {
+        sc[i] = g->data[i] * (1.0f / sqrtf(rv->data[i] + 1e-5f));
+        sh[i] = b->data[i] - rm->data[i] * sc[i];
+      }
+      RET(upload_vec(c, &c->stem.scale, sc, c->stem.Cout_pad));
+      RET(upload_vec(c, &c->stem.shift, sh, c->stem.Cout_pad));
     }
-    RET(upload_vec(c, &c->stem_scale, sc, 64));
-    RET(upload_vec(c, &c->stem_shift, sh, 64));
     const int nb50[4] = {3, 4, 6, 3}, nb101[4] = {3, 4, 23, 3}, nb152[4] = {3, 8, 36, 3};
     const int* nb = c->cfg.resnet_depth == 50 ? nb50 : (c->cfg.resnet_depth == 101 ? nb101 : nb152);
     c->stages.resize(4);
