@@ -32,6 +32,7 @@ struct ConvArgs {
   const void* res;    // optional residual (compute dtype), row stride res_ld
   const float* scale; // per-output-channel epilogue scale (nullptr -> 1)
   const float* shift; // per-output-channel epilogue shift (nullptr -> 0)
+  const void* zeros;  // >= 128 B of zeros: source of out-of-image taps (global_load_lds cannot predicate)
   const SegDesc* segs;
   const int2* tiles;  // tiles[t] = {segment, first row of the tile inside the segment}
   int n_mtiles, n_ntiles;
@@ -40,7 +41,6 @@ struct ConvArgs {
   int relu_nch;               // ReLU on output channels < relu_nch
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
-  int in_relu;                // apply ReLU to the input while staging (P7 = conv(relu(P6)))
   int stem;                   // ResNet-stem A loader (see conv_igemm.hip)
   int tap_dy;                 // input rows advanced per kernel-row tap (1; stem: rows per K-slice)
 };
@@ -87,5 +87,6 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 // conv_igemm.hip
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);
 void conv_pick_tile(int rows_total, int cout, int* BM, int* BN);
+void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 
 }  // namespace sylph

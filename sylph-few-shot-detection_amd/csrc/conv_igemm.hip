@@ -5,24 +5,35 @@
 // GEMM view: M = output positions (rows of the position-major activation buffer), N = Cout,
 // K = KH*KW*Cin walked tap-major in 128-byte slices (64 bf16 / 32 fp32), so a K-slice never
 // straddles a tap and the A operand of a slice is one 128-byte span of one input row: the im2col
-// gather is a per-row address + a 9-bit validity mask computed once per tile.
-// Both operands are K-contiguous ([pos][C] activations, [n][kh][kw][c] weights), which is the
-// layout the 32x32 MFMA fragments want (8 bf16 / 1 fp32 along K per lane).
+// gather is a per-row address + a validity mask computed once per tile.  Both operands are
+// K-contiguous ([pos][C] activations, [n][kh][kw][c] weights): the layout the 32x32 MFMA
+// fragments want (8 bf16 / 1 fp32 along K per lane).
 //
 // Block = 256 threads = 4 wave64 arranged WGM x WGN; wave tile (BM/WGM) x (BN/WGN) made of
-// 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, or the exact-fp32 v_mfma_f32_32x32x2_f32 in
-// parity mode).  Global->register->LDS staging, LDS double-buffered, one barrier per K-slice.
-// LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 so the
-// ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-byte slots.
-// Epilogue (fused): per-channel scale/shift (FrozenBN or bias), residual add (optionally through
-// a nearest 2x upsample: the FPN top-down path), per-segment Scale_l, ReLU, store bf16/fp32.
-// Reference ops replaced: every F.conv2d / nn.Conv2d on the path: ResNet bottleneck
-// convs + FrozenBN (detectron2), FPN lateral/output/P6/P7, FCOS towers (fcos.py:72-122),
+// 32x32 MFMA tiles (v_mfma_f32_32x32x16_bf16, or the exact-fp32 v_mfma_f32_32x32x2_f32 in parity mode).
+//
+// Staging: global_load_lds_dwordx4 (HBM/L2 -> LDS directly, no VGPR round trip, no ds_write).
+// One wave instruction lands 64 x 16 B = 8 LDS rows of 128 B.  The LDS image is lane-linear, so the
+// bank-conflict swizzle lives on the SOURCE side: lane (row r, slot s) fetches logical 16-byte
+// chunk s ^ ((r>>1)&7) of its row, and the ds_read_b128 fragment reads apply the same XOR, so
+// the 16 lanes of a read group hit 16 distinct slots.  Out-of-image taps (and rows past the end
+// of a segment) fetch from a zero page instead of branching.
+// NBUF = 1: one 128-byte slice resident (LDS (BM+BN)*128 B, two barriers per slice, latency hidden
+// by 3-4 co-resident blocks per CU); NBUF = 2: next slice in flight during the MFMAs.
+//
+// Epilogue (fused): accumulators -> LDS (fp32) -> per lane 8 consecutive channels: per-channel
+// scale/shift (FrozenBN or bias), residual add (optionally through a nearest 2x upsample: the FPN
+// top-down path), per-segment Scale_l, ReLU, 16-byte stores.
+// Reference ops replaced: every F.conv2d / nn.Conv2d on the path: ResNet stem and
+// bottleneck convs + FrozenBN (detectron2), FPN lateral/output/P6/P7, FCOS towers (fcos.py:72-122),
 // bbox_pred/ctrness (fcos.py:656-664), CondConvBasic (head_utils.py:60-81), code-generator
 // convs (code_generator.py:509-688).
 #include "common.h"
 
 namespace sylph {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <typename T> struct Mma;
 
@@ -52,34 +63,18 @@ template <> struct Mma<float> {
   }
 };
 
-__device__ __forceinline__ uint4 relu_pack(uint4 v, float) {
-  float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) f[i] = f[i] > 0.f ? f[i] : 0.f;
-  return v;
-}
-__device__ __forceinline__ uint4 relu_pack(uint4 v, bf16_t) {
-  uint32_t* u = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t neg = (u[i] >> 15) & 0x00010001u;  // sign bits of the two halves
-    u[i] &= ~(neg * 0xffffu);
-  }
-  return v;
-}
-
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN>
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AR = BM / 32, BR = BN / 32;  // rows staged per thread
+  constexpr int AR = BM / 32, BR = BN / 32;  // wave-level loads per slice (8 rows each)
+  constexpr int STAGE = (BM + BN) * 128;
   static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad tile");
+  static_assert(WTM * BN * 4 <= NBUF * STAGE, "epilogue tile does not fit the staging LDS");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sA = smem;                   // [2][BM][128]
-  char* const sB = smem + 2 * BM * 128;    // [2][BN][128]
 
   // XCD-aware block -> tile map: XCD x owns a contiguous chunk of M-tiles; inside it the N index
   // is innermost so consecutive blocks of one XCD share the A tile through that XCD's L2.
@@ -94,6 +89,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int c16 = tid & 7, r0 = tid >> 3;
+  const int cl = c16 ^ ((r0 >> 1) & 7);  // logical chunk this lane fetches (source-side swizzle)
 
   const int2 tile = a.tiles[mt];
   const SegDesc sd = a.segs[tile.x];
@@ -101,6 +97,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
   const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+  const T* __restrict__ zero = reinterpret_cast<const T*>(a.zeros);
   const int Cin = a.Cin, KW = a.KW, ntaps = a.KH * a.KW;
   const int cpt = Cin / BK;            // K-slices per tap
   const int nk = ntaps * cpt;
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       // 8-pixel window [2*ox-4, 2*ox+4) x 4 channels (window pixel 0 and channel 3 carry zero
       // weights), so every 16-byte chunk is PPC whole, aligned pixels of one input row.
       constexpr int PPC = EPC / 4, CPR = 8 / PPC, RPS = 8 / CPR;
-      const int khl = c16 / CPR, pxo = (c16 % CPR) * PPC;
+      const int khl = cl / CPR, pxo = (cl % CPR) * PPC;
       const int iy0 = oy * 2 - 3 + khl, ixw = ox * 2 - 4 + pxo;
       abase[i] = (sd.in_row0 + iy0 * sd.in_W + ixw) * 4;
       for (int t = 0; t < ntaps; ++t) {
@@ -129,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       }
     } else {
       const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-      abase[i] = (sd.in_row0 + iy0 * sd.in_W + ix0) * a.in_ld + c16 * EPC;
+      abase[i] = (sd.in_row0 + iy0 * sd.in_W + ix0) * a.in_ld + cl * EPC;
       for (int t = 0; t < ntaps; ++t) {
         const int kh = t / KW, kw = t - kh * KW;
         const bool ok = rv && (unsigned)(iy0 + kh) < (unsigned)sd.in_H && (unsigned)(ix0 + kw) < (unsigned)sd.in_W;
@@ -140,38 +137,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
   size_t bbase[BR];
 #pragma unroll
-  for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + 32 * j) * Ktot + c16 * EPC;
+  for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + 32 * j) * Ktot + cl * EPC;
 
-  uint4 ra[AR], rb[BR];
   int tap = 0, cc = 0, kh = 0, kw = 0;  // state of the NEXT slice to fetch
-  auto fetch = [&]() {
+  auto issue = [&](int buf) {
+    char* dA = smem + buf * STAGE + wave * 8 * 128;  // wave-uniform: lane l lands at +16*l
+    char* dB = dA + BM * 128;
     const int aoff = (kh * a.tap_dy * sd.in_W + kw) * a.in_ld + cc * BK;
     const int boff = tap * Cin + cc * BK;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((amask[i] >> tap) & 1u) v = *reinterpret_cast<const uint4*>(in + (abase[i] + aoff));
-      ra[i] = v;
+      const T* src = ((amask[i] >> tap) & 1u) ? in + (abase[i] + aoff) : zero + cl * EPC;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dA + i * 32 * 128), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < BR; ++j) rb[j] = *reinterpret_cast<const uint4*>(wt + (bbase[j] + boff));
+    for (int j = 0; j < BR; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + (bbase[j] + boff)), (lds_ptr_t)(dB + j * 32 * 128), 16, 0, 0);
     if (++cc == cpt) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
-  };
-  auto stash = [&](int buf) {
-    char* dA = sA + buf * BM * 128;
-    char* dB = sB + buf * BN * 128;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int row = r0 + 32 * i;
-      uint4 v = ra[i];
-      if (a.in_relu) v = relu_pack(v, T());
-      *reinterpret_cast<uint4*>(dA + row * 128 + ((c16 ^ ((row >> 1) & 7)) * 16)) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const int row = r0 + 32 * j;
-      *reinterpret_cast<uint4*>(dB + row * 128 + ((c16 ^ ((row >> 1) & 7)) * 16)) = rb[j];
-    }
   };
 
   f32x16 acc[TM][TN];
@@ -182,14 +164,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  fetch();
-  stash(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) fetch();
-    const char* tA = sA + buf * BM * 128;
-    const char* tB = sB + buf * BN * 128;
+  auto compute = [&](int buf) {
+    const char* tA = smem + buf * STAGE;
+    const char* tB = tA + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
       typename Mma<T>::frag_t fa[TM], fb[TN];
@@ -202,35 +179,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
     }
-    if (kt + 1 < nk) stash(buf ^ 1);
+  };
+
+  if (NBUF == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      issue(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) issue(buf ^ 1);
+      compute(buf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   // ---- fused epilogue ---------------------------------------------------------------------------
-  // accumulators -> LDS as fp32 [BM][BN] (aliases the staging buffers; the K loop ended on a
-  // barrier), then every lane owns 8 consecutive channels of one row: 16-byte residual loads and
-  // 16-byte (bf16) / 32-byte (fp32) stores, 256 B contiguous per 16 lanes.
-  static_assert(BM * BN * 4 <= 2 * (BM + BN) * 128, "epilogue tile does not fit the staging LDS");
+  // One pass per wave-row: its waves park their accumulators in LDS as fp32 [WTM][BN] (aliasing the
+  // staging buffers; the K loop ended on a barrier), then every lane owns 8 consecutive channels of
+  // one row: 16-byte residual loads, 16-byte (bf16) / 32-byte (fp32) stores, 256 B per 16 lanes.
   float* const sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = wn * WTN + j * 32 + (lane & 31);
-        sC[row * BN + col] = acc[i][j][r];
-      }
-  __syncthreads();
-
   constexpr int TPR = BN / 8;     // lanes per output row
-  constexpr int RPP = 256 / TPR;  // rows per pass
+  constexpr int RPP = 256 / TPR;  // rows per sweep
   OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(a.res);
   const int c8 = tid % TPR, rr = tid / TPR;
   const int n0 = nt * BN + c8 * 8;
-  if (n0 >= a.Cout) return;
+  const bool active = n0 < a.Cout;
   const bool vec = (n0 + 8 <= a.Cout) && ((a.out_ld & 7) == 0) && (a.res_mode == 0 || (a.res_ld & 7) == 0);
   float sc[8], sh[8];
 #pragma unroll
@@ -239,67 +222,92 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     sc[e] = (nv && a.scale) ? a.scale[n0 + e] : 1.f;
     sh[e] = (nv && a.shift) ? a.shift[n0 + e] : 0.f;
   }
-  for (int row = rr; row < BM; row += RPP) {
-    const int pos = tile.y + row;
-    if (pos >= seg_rows) break;
-    float v[8];
-    {
-      const float4 lo = *reinterpret_cast<const float4*>(sC + row * BN + c8 * 8);
-      const float4 hi = *reinterpret_cast<const float4*>(sC + row * BN + c8 * 8 + 4);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  for (int p = 0; p < WGM; ++p) {
+    if (p > 0) __syncthreads();
+    if (wm == p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = wn * WTN + j * 32 + (lane & 31);
+            sC[row * BN + col] = acc[i][j][r];
+          }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-    if (a.res_mode != 0) {
-      int rp = pos;
-      if (a.res_mode == 2) {
-        const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
-        rp = (oy >> 1) * sd.res_W + (ox >> 1);
+    __syncthreads();
+    if (!active) continue;
+    for (int rl = rr; rl < WTM; rl += RPP) {
+      const int pos = tile.y + p * WTM + rl;
+      if (pos >= seg_rows) break;
+      float v[8];
+      {
+        const float4 lo = *reinterpret_cast<const float4*>(sC + rl * BN + c8 * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(sC + rl * BN + c8 * 8 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       }
-      const T* rptr = res + (size_t)(sd.res_row0 + rp) * a.res_ld + n0;
-      if (vec) {
-        float rv[8];
-        load8<T>(rptr, rv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+      if (a.res_mode != 0) {
+        int rp = pos;
+        if (a.res_mode == 2) {
+          const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+          rp = (oy >> 1) * sd.res_W + (ox >> 1);
+        }
+        const T* rptr = res + (size_t)(sd.res_row0 + rp) * a.res_ld + n0;
+        if (vec) {
+          float rv[8];
+          load8<T>(rptr, rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        } else {
+          for (int e = 0; e < 8; ++e)
+            if (n0 + e < a.Cout) v[e] += Cvt<T>::to_f(rptr[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n0 + e < a.mul_nch) v[e] *= sd.mul;
+        if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      OutT* optr = out + (size_t)(sd.out_row0 + pos) * a.out_ld + n0;
+      if (vec) {
+        store8<OutT>(optr, v);
       } else {
         for (int e = 0; e < 8; ++e)
-          if (n0 + e < a.Cout) v[e] += Cvt<T>::to_f(rptr[e]);
+          if (n0 + e < a.Cout) optr[e] = Cvt<OutT>::from_f(v[e]);
       }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (n0 + e < a.mul_nch) v[e] *= sd.mul;
-      if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
-    }
-    OutT* optr = out + (size_t)(sd.out_row0 + pos) * a.out_ld + n0;
-    if (vec) {
-      store8<OutT>(optr, v);
-    } else {
-      for (int e = 0; e < 8; ++e)
-        if (n0 + e < a.Cout) optr[e] = Cvt<OutT>::from_f(v[e]);
     }
   }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN>
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  const size_t lds = 2 * (BM + BN) * 128;
-  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN>;
+  const size_t lds = (size_t)NBUF * (BM + BN) * 128;
+  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   return (int)hipGetLastError();
 }
 
+static int g_nbuf = 1;
+void conv_set_nbuf(int n) { g_nbuf = n == 2 ? 2 : 1; }
+
+template <typename T, typename OutT, int NBUF>
+static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
+  if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2, NBUF>(a, s);
+  if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2, NBUF>(a, s);
+  if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1, NBUF>(a, s);
+  if (BM == 64 && BN == 128) return launch_cfg<T, OutT, 64, 128, 2, 2, NBUF>(a, s);
+  if (BM == 64 && BN == 64) return launch_cfg<T, OutT, 64, 64, 2, 2, NBUF>(a, s);
+  return -1;
+}
+
 template <typename T, typename OutT>
 static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
-  if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2>(a, s);
-  if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2>(a, s);
-  if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1>(a, s);
-  if (BM == 64 && BN == 128) return launch_cfg<T, OutT, 64, 128, 2, 2>(a, s);
-  if (BM == 64 && BN == 64) return launch_cfg<T, OutT, 64, 64, 2, 2>(a, s);
-  return -1;
+  return g_nbuf == 2 ? launch_n<T, OutT, 2>(a, BM, BN, s) : launch_n<T, OutT, 1>(a, BM, BN, s);
 }
 
 // Tile choice: widest N tile the layer fills; drop to BM=64 when the grid would not fill 256 CUs.
@@ -308,7 +316,7 @@ void conv_pick_tile(int rows_total, int cout, int* BM, int* BN) {
   int bm = 128;
   if (bn != 32) {
     const long blocks128 = (long)((rows_total + 127) / 128) * ((cout + bn - 1) / bn);
-    if (blocks128 < 512) bm = 64;
+    if (blocks128 < 1024) bm = 64;
   }
   *BM = bm;
   *BN = bn;
@@ -318,6 +326,7 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipSt
   if (a.KH * a.KW > 32) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
   if (a.Cin % bk != 0) return -4;
+  if (!a.zeros) return -5;
   if (dt == DT_BF16) {
     return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);
   }

@@ -1,11 +1,12 @@
-// HBM-bound kernels of the Sylph inference path (gfx950): pixel normalisation + padding, ResNet stem
-// (7x7 s2 conv + FrozenBN + ReLU, direct fp32 FMA with wave-uniform weights), 3x3 s2 max-pool,
+// HBM-bound kernels of the Sylph inference path (gfx950): pixel normalisation + padding,
+// 3x3 s2 max-pool, row-wise ReLU copy,
 // GroupNorm(32 groups x 8 channels) statistics / apply(+ReLU), layout import/export.
 // All activation traffic is 16 bytes per lane (8 bf16 or 2x float4), rows are channel-contiguous.
 //
 // Reference ops replaced (paths relative to /root/reference):
 //   preprocess  : sylph/modeling/meta_arch/meta_one_stage_detector.py:174-178 (+ d2 ImageList.from_tensors)
-//   stem/maxpool: detectron2 BasicStem, called via meta_one_stage_detector.py:181,273
+//   maxpool     : detectron2 BasicStem max_pool2d(3, 2, 1), via meta_one_stage_detector.py:181,273
+//   relu_rows   : the F.relu(p6) feeding P7 in AdelaiDet LastLevelP6P7
 //   GroupNorm   : nn.GroupNorm(32, C) in sylph/modeling/meta_fcos/fcos.py:97-98 and
 //                 sylph/modeling/code_generator/code_generator.py:648-688 (build_fpn_norm "GN")
 #include "common.h"
@@ -43,74 +44,6 @@ int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int
   else
     hipLaunchKernelGGL(preprocess_kernel<float>, grid, block, 0, s, imgs_dev, (float*)out, H, W, mean[0], mean[1],
                        mean[2], 1.f / stdv[0], 1.f / stdv[1], 1.f / stdv[2]);
-  return (int)hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// stem: in [B][H][W][4], w fp32 [7][7][3][64] (wave-uniform index -> scalar loads), out [B][Ho][Wo][64]
-template <typename T> __device__ __forceinline__ void load_px3(const T* p, float& a, float& b, float& c);
-template <> __device__ __forceinline__ void load_px3<float>(const float* p, float& a, float& b, float& c) {
-  const float4 v = *reinterpret_cast<const float4*>(p);
-  a = v.x; b = v.y; c = v.z;
-}
-template <> __device__ __forceinline__ void load_px3<bf16_t>(const bf16_t* p, float& a, float& b, float& c) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p);
-  a = __uint_as_float(v.x << 16); b = __uint_as_float(v.x & 0xffff0000u); c = __uint_as_float(v.y << 16);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const T* __restrict__ in, const float* __restrict__ w,
-                                                        const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, T* __restrict__ out, int H,
-                                                        int W, int Ho, int Wo) {
-  const int b = blockIdx.z, oy = blockIdx.y;
-  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = ox < Wo;
-  float acc[64];
-#pragma unroll
-  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
-  const int iy0 = oy * 2 - 3, ix0 = ox * 2 - 3;
-  for (int kh = 0; kh < 7; ++kh) {
-    const int iy = iy0 + kh;
-    if ((unsigned)iy >= (unsigned)H) continue;  // uniform per block
-    const T* rowp = in + ((size_t)b * H + iy) * W * 4;
-#pragma unroll
-    for (int kw = 0; kw < 7; ++kw) {
-      const int ix = ix0 + kw;
-      float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-      if (active && (unsigned)ix < (unsigned)W) load_px3<T>(rowp + (size_t)ix * 4, p0, p1, p2);
-      const float* wp = w + (kh * 7 + kw) * 3 * 64;
-#pragma unroll
-      for (int c = 0; c < 64; ++c) {
-        acc[c] = fmaf(p0, wp[c], acc[c]);
-        acc[c] = fmaf(p1, wp[64 + c], acc[c]);
-        acc[c] = fmaf(p2, wp[128 + c], acc[c]);
-      }
-    }
-  }
-  if (!active) return;
-  T* o = out + (((size_t)b * Ho + oy) * Wo + ox) * 64;
-#pragma unroll
-  for (int c0 = 0; c0 < 64; c0 += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float t = acc[c0 + j] * scale[c0 + j] + shift[c0 + j];
-      v[j] = t > 0.f ? t : 0.f;
-    }
-    store8<T>(o + c0, v);
-  }
-}
-
-int launch_stem(DType dt, const void* in, const float* w, const float* scale, const float* shift, void* out, int B,
-                int H, int W, int Ho, int Wo, hipStream_t s) {
-  dim3 grid((Wo + 255) / 256, Ho, B), block(256);
-  if (dt == DT_BF16)
-    hipLaunchKernelGGL(stem_conv_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)in, w, scale, shift, (bf16_t*)out,
-                       H, W, Ho, Wo);
-  else
-    hipLaunchKernelGGL(stem_conv_kernel<float>, grid, block, 0, s, (const float*)in, w, scale, shift, (float*)out, H,
-                       W, Ho, Wo);
   return (int)hipGetLastError();
 }
 
@@ -284,6 +217,32 @@ int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int ma
   else
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, rpc, stats, gamma, beta,
                        relu);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// dst rows = relu(src rows), 8 channels per lane; grid (chunks, segments)
+template <typename T>
+__global__ void relu_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int ld, const CopySeg* segs) {
+  const CopySeg sg = segs[blockIdx.y];
+  const int per_row = ld / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= sg.nrows * per_row) return;
+  const int r = idx / per_row, c = (idx - r * per_row) * 8;
+  float v[8];
+  load8<T>(src + (size_t)(sg.src_row0 + r) * ld + c, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+  store8<T>(dst + (size_t)(sg.dst_row0 + r) * ld + c, v);
+}
+
+int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg* segs_dev, int nseg, int max_rows,
+                     hipStream_t s) {
+  dim3 grid((max_rows * (ld / 8) + 255) / 256, nseg), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(relu_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, ld, segs_dev);
+  else
+    hipLaunchKernelGGL(relu_rows_kernel<float>, grid, block, 0, s, (const float*)src, (float*)dst, ld, segs_dev);
   return (int)hipGetLastError();
 }
 

@@ -60,11 +60,12 @@ struct ImageOut { float sx, sy, out_w, out_h; };  // postprocess scale + clip bo
 // elementwise.hip
 int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int H, int W, const float* mean,
                       const float* stdv, hipStream_t s);
-int launch_stem(DType dt, const void* in, const float* w, const float* scale, const float* shift, void* out, int B,
-                int H, int W, int Ho, int Wo, hipStream_t s);
 int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s);
+struct CopySeg { int src_row0, dst_row0, nrows; };
+int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg* segs_dev, int nseg, int max_rows,
+                     hipStream_t s);
 int launch_import_nchw(DType dt, const float* src, void* dst, int C, int HW, int row0, int ld, hipStream_t s);
 int launch_export_nchw(DType dt, const void* src, float* dst, int C, int HW, int row0, int ld, hipStream_t s);
 int launch_export_nchw_f32(const float* src, float* dst, int C, int HW, int row0, int ld, int ch0, hipStream_t s);

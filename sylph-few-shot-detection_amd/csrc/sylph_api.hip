@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -95,6 +96,7 @@ struct sylph_ctx {
   // plans
   std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
   Plan* cur = nullptr;
+  void* zeros = nullptr;  // 256 B of zeros (conv out-of-image taps)
   // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
   bool prof = false;
   struct ProfRec { hipEvent_t a, b; double flops; };
@@ -311,7 +313,6 @@ struct ConvOpts {
   int relu_nch = 0, mul_nch = 0;
   const void* res = nullptr;
   int res_ld = 0, res_mode = 0;
-  int in_relu = 0;
   bool out_f32 = false;
   int cout_override = -1;  // logical Cout (class-conditional conv)
   int stem = 0;            // ResNet stem loader
@@ -330,12 +331,12 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in; a.wt = L.w; a.out = out; a.res = o.res;
-  a.scale = L.scale; a.shift = L.shift;
+  a.scale = L.scale; a.shift = L.shift; a.zeros = c->zeros;
   a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;
   a.Cin = L.Cin; a.Cout = o.cout_override >= 0 ? o.cout_override : L.Cout;
   a.KH = L.KH; a.KW = L.KW; a.stride = o.stride; a.pad = o.pad;
   a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
-  a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode; a.in_relu = o.in_relu;
+  a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode;
   a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
   const DType dt = c->dt;
   const bool of32 = o.out_f32;
@@ -466,8 +467,24 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
       sg[b].in_row0 = b * P->Ltot + P->off[k - 1];
       sg[b].out_row0 = b * P->Ltot + P->off[k];
     }
-    ConvOpts op; op.stride = 2; op.pad = 1; op.in_relu = (k == 4) ? 1 : 0;
-    RET(add_conv(c, ops, k == 3 ? c->p6 : c->p7, P->F, 256, P->F, 256, sg, op));
+    ConvOpts op; op.stride = 2; op.pad = 1;
+    const void* src = P->F;
+    if (k == 4) {  // P7 = conv(relu(P6)): rectified copy of the P6 rows
+      const int n6 = P->hl[3] * P->wl[3];
+      void* p6r;
+      RET(c->dalloc(&p6r, (size_t)B * n6 * 256 * e));
+      std::vector<CopySeg> cs;
+      for (int b = 0; b < B; ++b) {
+        cs.push_back(CopySeg{b * P->Ltot + P->off[3], b * n6, n6});
+        sg[b].in_row0 = b * n6;
+      }
+      CopySeg* csd;
+      RET(upload(c, (void**)&csd, cs.data(), cs.size() * sizeof(CopySeg)));
+      const void* F = P->F;
+      ops.push_back([=](hipStream_t s) { return launch_relu_rows(dt, F, p6r, 256, csd, B, n6, s); });
+      src = p6r;
+    }
+    RET(add_conv(c, ops, k == 3 ? c->p6 : c->p7, src, 256, P->F, 256, sg, op));
   }
   P->backbone_built = true;
   return 0;
@@ -699,6 +716,11 @@ int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out) {
   c->device = device_id;
   c->dt = dtype == SYLPH_BF16 ? DT_BF16 : DT_F32;
   sylph_config_default(&c->cfg);
+  if (const char* nb = getenv("SYLPH_CONV_NBUF")) conv_set_nbuf(atoi(nb));  // tuning knob: LDS stages of the conv kernel
+  if (c->dalloc(&c->zeros, 256) != 0 || hipMemset(c->zeros, 0, 256) != hipSuccess) {
+    delete c;
+    return fail("cannot allocate the zero page");
+  }
   *out = c;
   return 0;
 }
@@ -932,6 +954,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   memset(&a, 0, sizeof(a));
   a.in = P->cls_feat; a.wt = P->code_w; a.out = P->logits;
   a.shift = (c->cfg.cond_use_bias && cls_bias) ? cls_bias : nullptr;
+  a.zeros = c->zeros; a.tap_dy = 1;
   a.segs = P->head_segs;
   int BM = P->head_BM;
   if (bn == 32) { BM = 128; a.tiles = P->head_tiles32; a.n_mtiles = P->head_mtiles32; }
@@ -1019,7 +1042,7 @@ int sylph_conv2d(sylph_ctx* c, const float* x, int B, int C, int H, int W, const
   if (C % bk != 0) return fail("sylph_conv2d: Cin must be a multiple of " + std::to_string(bk));
   const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   sylph_ctx tmp;  // scratch allocations freed on return
-  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream;
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros;
   struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
   HostTensor hw;
   hw.shape = {Cout, C, KH, KW};
@@ -1054,7 +1077,7 @@ int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const fl
                      int relu, float* y) {
   HIPCHK(hipSetDevice(c->device));
   sylph_ctx tmp;
-  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream;
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros;
   struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
   const int HW = H * W;
   void* buf;
