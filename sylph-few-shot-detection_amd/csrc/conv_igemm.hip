@@ -222,6 +222,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     sc[e] = (nv && a.scale) ? a.scale[n0 + e] : 1.f;
     sh[e] = (nv && a.shift) ? a.shift[n0 + e] : 0.f;
   }
+  // GroupNorm(32 x 8 channels) statistics of the fp32 outputs, fused: a lane's 8 channels are exactly
+  // one group; Chan/Welford running (count, mean, M2) per lane, combined in a fixed order below.
+  float gn_n = 0.f, gn_mean = 0.f, gn_m2 = 0.f;
   for (int p = 0; p < WGM; ++p) {
     if (p > 0) __syncthreads();
     if (wm == p) {
@@ -271,6 +274,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         if (n0 + e < a.mul_nch) v[e] *= sd.mul;
         if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
+      if (a.gn_partial) {
+        float s8 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8 += v[e];
+        const float m8 = s8 * 0.125f;
+        float q8 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - m8; q8 = fmaf(d, d, q8); }
+        const float nn = gn_n + 8.f, delta = m8 - gn_mean;
+        gn_mean += delta * (8.f / nn);
+        gn_m2 += q8 + delta * delta * (gn_n * 8.f / nn);
+        gn_n = nn;
+      }
       OutT* optr = out + (size_t)(sd.out_row0 + pos) * a.out_ld + n0;
       if (vec) {
         store8<OutT>(optr, v);
@@ -278,6 +294,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int e = 0; e < 8; ++e)
           if (n0 + e < a.Cout) optr[e] = Cvt<OutT>::from_f(v[e]);
       }
+    }
+  }
+  if (a.gn_partial) {
+    __syncthreads();
+    float* red = sC;  // [RPP][TPR][3]
+    red[(rr * TPR + c8) * 3 + 0] = gn_n;
+    red[(rr * TPR + c8) * 3 + 1] = gn_mean;
+    red[(rr * TPR + c8) * 3 + 2] = gn_m2;
+    __syncthreads();
+    if (rr == 0 && active) {
+      float N = 0.f, M = 0.f, Q = 0.f;
+      for (int r = 0; r < RPP; ++r) {
+        const float nb = red[(r * TPR + c8) * 3 + 0];
+        if (nb > 0.f) {
+          const float mb = red[(r * TPR + c8) * 3 + 1], qb = red[(r * TPR + c8) * 3 + 2];
+          const float nn = N + nb, delta = mb - M;
+          M += delta * (nb / nn);
+          Q += qb + delta * delta * (N * nb / nn);
+          N = nn;
+        }
+      }
+      float* gp = a.gn_partial + ((size_t)mt * (a.Cout >> 3) + (n0 >> 3)) * 3;
+      gp[0] = N; gp[1] = M; gp[2] = Q;
     }
   }
 }

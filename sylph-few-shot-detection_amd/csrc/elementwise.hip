@@ -198,6 +198,72 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
   }
 }
 
+// Fused variant: the conv epilogue already left (n, mean, M2) per (M-tile, group); every block folds
+// the partials of its segment in tile order (deterministic, fp64) and applies the affine (+ReLU).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ x, const GnSeg* segs, int ld,
+                                                                int rows_per_chunk,
+                                                                const float* __restrict__ partial, float eps,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int relu) {
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const GnSeg sg = segs[seg];
+  const int r_begin = chunk * rows_per_chunk;
+  if (r_begin >= sg.nrows) return;
+  const int r_end = min(sg.nrows, r_begin + rows_per_chunk);
+  const int g = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  __shared__ float2 st_sh[32];
+  if (threadIdx.x < 32) {
+    double N = 0.0, M = 0.0, Q = 0.0;
+    for (int t = 0; t < sg.ntiles; ++t) {
+      const float* p = partial + ((size_t)(sg.tile0 + t) * 32 + g) * 3;
+      const double nb = p[0], mb = p[1], qb = p[2];
+      if (nb > 0.0) {
+        const double nn = N + nb, delta = mb - M;
+        M += delta * (nb / nn);
+        Q += qb + delta * delta * (N * nb / nn);
+        N = nn;
+      }
+    }
+    const double var = N > 0.0 ? Q / N : 0.0;
+    st_sh[g] = make_float2((float)M, (float)(1.0 / sqrt(var + (double)eps)));
+  }
+  __syncthreads();
+  const float2 st = st_sh[g];
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = st.y * gamma[g * 8 + j];
+    b[j] = beta[g * 8 + j] - st.x * a[j];
+  }
+  for (int r = r_begin + rl; r < r_end; r += 8) {
+    T* p = x + (size_t)(sg.row0 + r) * ld + g * 8;
+    float v[8];
+    load8<T>(p, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = fmaf(v[j], a[j], b[j]);
+      if (relu) t = t > 0.f ? t : 0.f;
+      v[j] = t;
+    }
+    store8<T>(p, v);
+  }
+}
+
+int launch_gn_apply_partials(DType dt, void* x, int ld, const GnSeg* segs_dev, int nseg, int max_rows,
+                             const float* partial, const float* gamma, const float* beta, float eps, int relu,
+                             hipStream_t s) {
+  const int rpc = GN_ROWS_PER_CHUNK;
+  dim3 grid((max_rows + rpc - 1) / rpc, nseg), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, rpc, partial, eps,
+                       gamma, beta, relu);
+  else
+    hipLaunchKernelGGL(gn_apply_partials_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, rpc, partial, eps,
+                       gamma, beta, relu);
+  return (int)hipGetLastError();
+}
+
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s) {
   const int rpc = GN_ROWS_PER_CHUNK;

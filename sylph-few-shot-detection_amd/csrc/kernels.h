@@ -8,6 +8,8 @@ struct ImageDesc { const float* ptr; int h, w; };   // one (3,h,w) fp32 plane-ma
 struct RowSeg { int row0, nrows; };                 // a run of rows (one GroupNorm sample)
 
 constexpr int GN_ROWS_PER_CHUNK = 256;
+// a GroupNorm sample (= conv segment) whose statistics were left by the conv epilogue as per-M-tile partials
+struct GnSeg { int row0, nrows, tile0, ntiles; };
 
 // One (image, FPN level) slab of the head outputs, for decode.
 struct DecodeSeg {
@@ -63,6 +65,9 @@ int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int
 int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s);
+int launch_gn_apply_partials(DType dt, void* x, int ld, const GnSeg* segs_dev, int nseg, int max_rows,
+                             const float* partial, const float* gamma, const float* beta, float eps, int relu,
+                             hipStream_t s);
 struct CopySeg { int src_row0, dst_row0, nrows; };
 int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg* segs_dev, int nseg, int max_rows,
                      hipStream_t s);

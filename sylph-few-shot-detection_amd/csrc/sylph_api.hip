@@ -272,13 +272,17 @@ struct Geom {
   const SegDesc* segs;
   const int2* tiles;
   int n_mtiles;
+  std::vector<int2> seg_tiles;  // per segment: {first tile, tile count}
+  float* gn_partial = nullptr;  // per-tile GroupNorm partials written by the conv epilogue (want_gn)
 };
 
 static int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geom* g) {
   std::vector<int2> tiles;
   for (size_t s = 0; s < segs.size(); ++s) {
     const int rows = segs[s].out_H * segs[s].out_W;
+    const int t0 = (int)tiles.size();
     for (int r = 0; r < rows; r += BM) tiles.push_back(make_int2((int)s, r));
+    g->seg_tiles.push_back(make_int2(t0, (int)tiles.size() - t0));
   }
   void *ds = nullptr, *dtl = nullptr;
   RET(upload(c, &ds, segs.data(), segs.size() * sizeof(SegDesc)));
@@ -316,11 +320,12 @@ struct ConvOpts {
   bool out_f32 = false;
   int cout_override = -1;  // logical Cout (class-conditional conv)
   int stem = 0;            // ResNet stem loader
+  int want_gn = 0;         // leave per-tile GroupNorm partials in the epilogue
   double flops = -1.0;     // algorithmic FLOPs of the launch when they differ from 2*M*N*K (stem padding)
 };
 
 static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
-                    int out_ld, const std::vector<SegDesc>& segs, const ConvOpts& o) {
+                    int out_ld, const std::vector<SegDesc>& segs, const ConvOpts& o, Geom* geom_out = nullptr) {
   long rows = 0;
   for (auto& s : segs) rows += (long)s.out_H * s.out_W;
   int BM, BN;
@@ -338,10 +343,40 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode;
   a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
+  if (o.want_gn) {
+    if (L.Cout != 256) return fail("fused GroupNorm statistics need Cout == 256");
+    RET(c->dalloc((void**)&a.gn_partial, (size_t)g.n_mtiles * 32 * 3 * sizeof(float)));
+  }
+  if (geom_out) { *geom_out = g; geom_out->gn_partial = a.gn_partial; }
   const DType dt = c->dt;
   const bool of32 = o.out_f32;
   const double flops = o.flops >= 0.0 ? o.flops : 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
   ops.push_back([a, BM, BN, dt, of32, c, flops](hipStream_t s) { return timed_conv(c, dt, of32, a, BM, BN, flops, s); });
+  return 0;
+}
+
+// conv + GroupNorm(32, 256)(+ReLU): statistics fused into the conv epilogue, one in-place apply pass
+static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
+                       const std::vector<SegDesc>& segs, ConvOpts o, const GNLayer& G, int relu) {
+  o.want_gn = 1;
+  Geom g;
+  RET(add_conv(c, ops, L, in, in_ld, out, 256, segs, o, &g));
+  const float* partial = g.gn_partial;
+  std::vector<GnSeg> gs;
+  int max_rows = 0;
+  for (size_t s = 0; s < segs.size(); ++s) {
+    const int rows = segs[s].out_H * segs[s].out_W;
+    gs.push_back(GnSeg{segs[s].out_row0, rows, g.seg_tiles[s].x, g.seg_tiles[s].y});
+    max_rows = rows > max_rows ? rows : max_rows;
+  }
+  GnSeg* gsd;
+  RET(upload(c, (void**)&gsd, gs.data(), gs.size() * sizeof(GnSeg)));
+  const DType dt = c->dt;
+  const int nseg = (int)gs.size();
+  const float *ga = G.gamma, *be = G.beta;
+  ops.push_back([=](hipStream_t s) {
+    return launch_gn_apply_partials(dt, out, 256, gsd, nseg, max_rows, partial, ga, be, 1e-5f, relu, s);
+  });
   return 0;
 }
 
@@ -553,8 +588,7 @@ static int build_head(sylph_ctx* c, Plan* P) {
     void* out = b0;
     for (size_t i = 0; i < convs.size(); ++i) {
       ConvOpts o; o.pad = 1;
-      RET(add_conv(c, ops, convs[i], in, 256, out, 256, segs, o));
-      RET(add_gn(c, P, ops, out, P->head_rowsegs, nseg, max_rows, gns[i], 1));
+      RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1));
       in = out;
       out = (out == b0) ? b1 : b0;
     }
@@ -657,8 +691,7 @@ static int build_support(sylph_ctx* c, Plan* P) {
   void* out = P->cgA;
   for (size_t i = 0; i < c->cg_tower.size(); ++i) {
     ConvOpts o; o.pad = 1;
-    RET(add_conv(c, ops, c->cg_tower[i], in, 256, out, 256, segs, o));
-    RET(add_gn(c, P, ops, out, rs_dev, S, npos, c->cg_gn[i], 1));
+    RET(add_conv_gn(c, ops, c->cg_tower[i], in, 256, out, segs, o, c->cg_gn[i], 1));
     in = out;
     out = (out == P->cgA) ? P->cgB : P->cgA;
   }
