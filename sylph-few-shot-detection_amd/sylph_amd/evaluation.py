@@ -1,0 +1,172 @@
+"""Episodic inference loops and class-code formatting with the reference's signatures
+(sylph/evaluation/meta_learn_evaluation.py:71-470).  The loops are host control flow only; the
+model they drive enqueues HIP kernels.  Timing/log lines follow the reference protocol (warm-up
+iterations excluded, "s / img", "s / class code")."""
+import logging
+import os
+import time
+from collections import defaultdict
+from contextlib import ExitStack, contextmanager
+from typing import Any, Dict, List
+
+import torch
+from torch import nn
+
+from .distributed import get_world_size
+
+logger = logging.getLogger(__name__)
+
+
+@contextmanager
+def inference_context(model: nn.Module):
+    """detectron2.evaluation.inference_context: temporarily eval()."""
+    mode = model.training
+    model.eval()
+    try:
+        yield
+    finally:
+        model.train(mode)
+
+
+def format_class_codes_shared(class_codes: List[Dict[str, Any]], device) -> Dict[str, torch.Tensor]:
+    """meta_learn_evaluation.py:71-103: order by support_set_target, concatenate, flatten cls_bias."""
+    num_classes = len(class_codes)
+    if num_classes == 0:
+        return class_codes
+    outs = defaultdict(list)
+    for k in class_codes[0]["class_code"].keys():
+        outs[k] = [None for _ in range(num_classes)]
+    for code in class_codes:
+        for dtype, value in code["class_code"].items():
+            if dtype == "snnl":
+                continue
+            outs[dtype][int(code["support_set_target"])] = value
+    final = {}
+    for key, value in outs.items():
+        final[key] = torch.cat([v.to(device) for v in value], dim=0)
+        if key == "cls_bias":
+            final[key] = final[key].view(final[key].numel())
+    return final
+
+
+def inference_normalization(model, codes: List[Dict[str, Any]]):
+    """meta_learn_evaluation.py:105-116."""
+    logger.info(f"Start normalizing class codes on {get_world_size()} devices")
+    with ExitStack() as stack:
+        if isinstance(model, nn.Module):
+            stack.enter_context(inference_context(model))
+        stack.enter_context(torch.no_grad())
+        return model(batched_inputs=None, class_code=codes, run_type="meta_learn_normalize_code")
+
+
+def _log_totals(kind: str, unit: str, total_time: float, compute_time: float, n: int, devices: int):
+    logger.info("Total inference time: {:.3f}s ({:.6f} s / {} per device, on {} devices)".format(
+        total_time, total_time / max(n, 1), unit, devices))
+    logger.info("Total inference pure compute time: {:.3f}s ({:.6f} s / img per device, on {} devices)".format(
+        compute_time, compute_time / max(n, 1), devices))
+
+
+def inference_on_support_set_dataset(model, data_loader, output_dir: str = None) -> List[Dict[str, Any]]:
+    """Loop A (meta_learn_evaluation.py:256-365): one item = one class {"support_set", "support_set_target",
+    "class_name"}; returns [{support_set_target, class_name, class_code}] and optionally writes
+    <output_dir>/<class_name>.pth (the file SylphPredictor reads, sylph/predictor.py:167-187)."""
+    devices = get_world_size()
+    total = len(data_loader)
+    logger.info(f"Start generating class codes on {total} support sets on {devices} devices")
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+    num_warmup = min(5, max(total - 1, 0))
+    start_time, compute = time.perf_counter(), 0.0
+    results = []
+    with ExitStack() as stack:
+        if isinstance(model, nn.Module):
+            stack.enter_context(inference_context(model))
+        stack.enter_context(torch.no_grad())
+        for idx, inputs in enumerate(data_loader):
+            assert len(inputs) == 1, "inputs' batch size is not 1"
+            if idx == num_warmup:
+                start_time, compute = time.perf_counter(), 0.0
+            result = {k: v for k, v in inputs[0].items() if k != "support_set"}
+            t0 = time.perf_counter()
+            class_code = model(inputs, run_type="meta_learn_test_support")
+            class_code = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in class_code.items()}  # device sync
+            compute += time.perf_counter() - t0
+            result["class_code"] = class_code
+            if output_dir is not None:
+                torch.save(result, os.path.join(output_dir, f"{result['class_name']}.pth"))
+            results.append(result)
+    _log_totals("support", "class code", time.perf_counter() - start_time, compute, total - num_warmup, devices)
+    return results
+
+
+def inference_on_support_set_dataset_base(model, data_loader, all_id_map=None, base_id_map=None,
+                                          output_dir: str = None) -> List[Dict[str, Any]]:
+    """Base-class variant (meta_learn_evaluation.py:118-254): a class arrives in chunks of <= 10 shots
+    carrying "len"/"total_len"; chunk codes are accumulated with weight len/total_len and the
+    accumulated weight is kept in "acc_weight" for the cross-rank reduce."""
+    results, acc, names = [], {}, {}
+    with ExitStack() as stack:
+        if isinstance(model, nn.Module):
+            stack.enter_context(inference_context(model))
+        stack.enter_context(torch.no_grad())
+        for inputs in data_loader:
+            assert len(inputs) == 1, "inputs' batch size is not 1"
+            code = model(inputs, run_type="meta_learn_test_support")
+            code = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in code.items()}
+            cid = int(inputs[0]["support_set_target"])
+            names[cid] = inputs[0]["class_name"]
+            weight = float(inputs[0]["len"]) / inputs[0]["total_len"]
+            if cid in acc:
+                acc[cid]["cls_conv"] += code["cls_conv"] * weight
+                acc[cid]["cls_bias"] += code["cls_bias"] * weight
+                acc[cid]["acc_weight"] += weight
+            else:
+                acc[cid] = {"cls_conv": code["cls_conv"] * weight, "cls_bias": code["cls_bias"] * weight,
+                            "acc_weight": weight}
+    for cid, cc in acc.items():
+        results.append({"support_set_target": cid, "class_name": names[cid], "class_code": cc})
+    return results
+
+
+class _NoOpEvaluator:
+    def reset(self):
+        pass
+
+    def process(self, inputs, outputs):
+        pass
+
+    def evaluate(self):
+        return {}
+
+
+def inference_on_dataset_with_class_codes(model, data_loader, evaluator, class_codes, cls_reweight=False,
+                                          eval_with_pretrained_code=False):
+    """Loop B (meta_learn_evaluation.py:367-470): model(inputs, class_code=..., run_type=
+    "meta_learn_test_instance") per query batch, evaluator.process(inputs, outputs), evaluator.evaluate()."""
+    devices = get_world_size()
+    if eval_with_pretrained_code:
+        raise NotImplementedError("eval_with_pretrained_code is out of scope (needs the base detector's cls_logits)")
+    assert class_codes is not None
+    if cls_reweight:
+        raise NotImplementedError("cls_reweight is not supported (CLS_REWEIGHT is False in every yaml)")
+    total = len(data_loader)
+    logger.info(f"Start inference with predicted class codes on {total} images")
+    evaluator = evaluator if evaluator is not None else _NoOpEvaluator()
+    evaluator.reset()
+    num_warmup = min(5, max(total - 1, 0))
+    start_time, compute = time.perf_counter(), 0.0
+    with ExitStack() as stack:
+        if isinstance(model, nn.Module):
+            stack.enter_context(inference_context(model))
+        stack.enter_context(torch.no_grad())
+        for idx, inputs in enumerate(data_loader):
+            if idx == num_warmup:
+                start_time, compute = time.perf_counter(), 0.0
+            t0 = time.perf_counter()
+            outputs = model(inputs, class_code=class_codes, run_type="meta_learn_test_instance")
+            # forward_instances ends on the count read-back: the device work of this batch is complete
+            compute += time.perf_counter() - t0
+            evaluator.process(inputs, outputs)
+    _log_totals("query", "img", time.perf_counter() - start_time, compute, total - num_warmup, devices)
+    results = evaluator.evaluate()
+    return results if results is not None else {}

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's meta-architecture for the inference path.
+
+    model(batched_inputs, class_code=None, run_type=None)
+
+keeps the reference's dispatch, argument meaning and error behaviour
+(sylph/modeling/meta_arch/meta_one_stage_detector.py:415-455) while every tensor op runs in
+libsylph_hip (one C-ABI call per stage, see sylph_amd/engine.py).  The registries keep the yaml
+names resolvable (MODEL.META_ARCHITECTURE "MetaOneStageDetector", MODEL.BACKBONE.NAME
+"build_fcos_resnet_fpn_backbone", MODEL.PROPOSAL_GENERATOR.NAME "MetaFCOS",
+MODEL.META_LEARN.CODE_GENERATOR.NAME "CodeGenerator"; sylph/modeling/code_generator/build.py:18-39).
+"""
+import logging
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .engine import Engine
+from .structures import Boxes, Instances
+
+logger = logging.getLogger(__name__)
+
+
+class Registry:
+    """name -> object, with the detectron2 Registry surface (register() decorator, get())."""
+
+    def __init__(self, name: str):
+        self._name = name
+        self._obj_map: Dict[str, Any] = {}
+
+    def register(self, obj: Any = None):
+        if obj is None:
+            def deco(o):
+                self._obj_map[o.__name__] = o
+                return o
+            return deco
+        self._obj_map[obj.__name__] = obj
+        return obj
+
+    def get(self, name: str) -> Any:
+        if name not in self._obj_map:
+            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+        return self._obj_map[name]
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._obj_map
+
+
+META_ARCH_REGISTRY = Registry("META_ARCH")
+BACKBONE_REGISTRY = Registry("BACKBONE")
+PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
+CODE_GENERATOR_REGISTRY = Registry("CODE_GENERATOR")
+
+
+@BACKBONE_REGISTRY.register()
+def build_fcos_resnet_fpn_backbone(cfg, input_shape=None):
+    """The backbone lives inside the HIP context; this entry validates the config it implies."""
+    if list(cfg.MODEL.FPN.IN_FEATURES) != ["res3", "res4", "res5"]:
+        raise NotImplementedError("FPN.IN_FEATURES must be [res3, res4, res5]")
+    if int(cfg.MODEL.FCOS.TOP_LEVELS) != 2:
+        raise NotImplementedError("MODEL.FCOS.TOP_LEVELS must be 2 (P6, P7 from p5)")
+    if str(cfg.MODEL.FPN.get("NORM", "")) != "":
+        raise NotImplementedError("MODEL.FPN.NORM is not supported")
+    return {"name": "build_fcos_resnet_fpn_backbone", "depth": int(cfg.MODEL.RESNETS.DEPTH), "size_divisibility": 32}
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+def MetaFCOS(cfg, input_shape=None):
+    return {"name": "MetaFCOS"}
+
+
+@CODE_GENERATOR_REGISTRY.register()
+def CodeGenerator(cfg, feature_channels=256, feature_levels=5, strides=None):
+    assert feature_channels == 256, "Each level must have the same channel!"
+    return {"name": "CodeGenerator"}
+
+
+@CODE_GENERATOR_REGISTRY.register()
+def ROIEncoder(cfg, feature_channels=256, feature_levels=5, strides=None):
+    raise NotImplementedError("the ROIEncoder code generator (SURVEY.md 8a a22) is not built yet")
+
+
+def build_code_generator(cfg, feature_channels, feature_levels, strides):
+    """sylph/modeling/code_generator/build.py:30-39."""
+    name = cfg.MODEL.META_LEARN.CODE_GENERATOR.NAME
+    return CODE_GENERATOR_REGISTRY.get(name)(cfg, feature_channels, feature_levels, strides)
+
+
+@META_ARCH_REGISTRY.register()
+class MetaOneStageDetector(nn.Module):
+    """Four inference forward types (meta_one_stage_detector.py:415-455):
+      run_type None                         -> NotImplementedError for an episodic model (as the reference)
+      "meta_learn_test_support"             -> forward_class_code
+      "meta_learn_normalize_code"           -> normalize_class_code
+      "meta_learn_test_instance"            -> forward_instances
+    Training is out of scope: calling the model in training mode raises NotImplementedError."""
+
+    def __init__(self, cfg, dtype: Optional[str] = None, device_index: Optional[int] = None):
+        super().__init__()
+        self.cfg = cfg
+        self.episodic_learning = bool(cfg.MODEL.META_LEARN.EPISODIC_LEARNING)
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg)
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg)
+        self.code_generator = (build_code_generator(cfg, 256, len(cfg.MODEL.FCOS.IN_FEATURES),
+                                                    cfg.MODEL.FCOS.FPN_STRIDES) if self.episodic_learning else None)
+        if self.episodic_learning:
+            assert self.code_generator is not None
+        self.in_features = list(cfg.MODEL.FCOS.IN_FEATURES)
+        if device_index is None:
+            dev = torch.device(cfg.MODEL.DEVICE)
+            device_index = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        dtype = dtype or str(cfg.MODEL.get("COMPUTE_DTYPE", "bf16"))
+        self.engine = Engine(cfg, dtype=dtype, device=device_index)
+        self.register_buffer("pixel_mean", torch.tensor(list(cfg.MODEL.PIXEL_MEAN), dtype=torch.float32,
+                                                        device=self.engine.device).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.tensor(list(cfg.MODEL.PIXEL_STD), dtype=torch.float32,
+                                                       device=self.engine.device).view(-1, 1, 1))
+        self._weights_loaded = False
+        self.train(True)  # nn.Module default; the runner / predictor call .eval()
+
+    # ---- reference surface -------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts the reference checkpoint's ["model"] dict (SURVEY.md 8b key layout)."""
+        self.engine.load_state_dict(state_dict)
+        self._weights_loaded = True
+        return self
+
+    def load_checkpoint(self, path: str):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        return self.load_state_dict(ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt)
+
+    def forward(self, batched_inputs, class_code=None, run_type=None):
+        if self.training:
+            raise NotImplementedError("training is out of scope of the MI355X inference path; call model.eval()")
+        if run_type is None:
+            if not self.episodic_learning:
+                raise NotImplementedError("base-detector inference (EPISODIC_LEARNING False) is out of scope")
+            raise NotImplementedError(
+                "Episodic learning inferrence for image and features is not supported in forward.")
+        if run_type == "meta_learn_test_support":
+            return self.forward_class_code(batched_inputs)
+        if run_type == "meta_learn_normalize_code":
+            return self.normalize_class_code(class_code)
+        if run_type == "meta_learn_test_instance":
+            return self.forward_instances(batched_inputs, class_code)
+        raise NotImplementedError(f"not support this forward type: {run_type}, class_code: {class_code}")
+
+    # ---- support path --------------------------------------------------------------------------------
+    def forward_class_code(self, batched_inputs: List[Dict[str, Any]]) -> Dict[str, torch.Tensor]:
+        """meta_one_stage_detector.py:229-254: ONE class, its S support records."""
+        assert not self.training, "Not for training"
+        assert len(batched_inputs) == 1, f"batched_inputs has length: {len(batched_inputs)}"
+        records = [rec for x in batched_inputs for rec in x["support_set"]]
+        boxes = []
+        for rec in records:
+            gt = rec["instances"].gt_boxes.tensor
+            if len(gt) == 0:  # select_a_mask (code_generator/utils.py:35-38)
+                logger.info("Run into empty box, use zero masks")
+                raise ValueError
+            if len(gt) > 1:
+                # the reference draws np.random.choice here (global RNG, utils.py:41); deterministic
+                # only when one box is given -- we require the caller to have selected it
+                import numpy as np
+                gt = gt[np.random.choice(range(len(gt)), 1)]
+            boxes.append(gt.reshape(1, 4))
+        eng = self.engine
+        eng.preprocess([rec["image"] for rec in records])
+        eng.backbone()
+        code = eng.codegen(torch.cat(boxes, dim=0))
+        return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
+
+    def normalize_class_code(self, codes: List[Dict]):
+        """code_generator.py:877-897 via meta_one_stage_detector.py:256-259 (mutates the list)."""
+        assert self.episodic_learning
+        assert not self.training
+        assert codes is not None
+        if len(codes) == 0:
+            return codes
+        rows = []
+        for code in codes:
+            assert "class_code" in code, "class_code is not in code"
+            assert "cls_conv" in code["class_code"], "class_conv is not in class_code"
+            if "cls_weight_norm" in code["class_code"]:
+                raise NotImplementedError("cls_weight_norm (SCALE_LAYER) is not supported")
+            cc = code["class_code"]
+            assert cc["cls_conv"].ndim == 4
+            assert cc["cls_bias"].numel() == 1, "predicted bias should only have batch size 1"
+            rows.append(torch.cat([cc["cls_conv"].reshape(-1).float(), cc["cls_bias"].reshape(-1).float()]))
+        packed = torch.stack(rows).to(self.device).contiguous()
+        out = self.engine.normalize_codes(packed)
+        for i, code in enumerate(codes):
+            code["class_code"]["cls_conv"] = out[i, :256].reshape(1, 256, 1, 1)
+            code["class_code"]["cls_bias"] = out[i, 256:257].reshape(1)
+        return codes
+
+    # ---- query path ----------------------------------------------------------------------------------
+    def forward_instances(self, batched_inputs: List[Dict[str, Any]], class_codes: Dict[str, torch.Tensor]):
+        """meta_one_stage_detector.py:261-296 -> [{"instances": Instances}] at input["height"/"width"] scale."""
+        assert self.episodic_learning
+        assert not self.training, "Not for training"
+        if class_codes is None:
+            raise NotImplementedError("evaluation with pretrained class codes (class_code=None) is out of scope")
+        w, b = class_codes["cls_conv"], class_codes.get("cls_bias")
+        assert w.dim() == 4, f"Weight has dimension: {w.dim()}"
+        assert w.size(1) == 256
+        eng = self.engine
+        images = [x["image"] for x in batched_inputs]
+        eng.preprocess(images)
+        eng.backbone()
+        eng.head(w, b)
+        sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        out_sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
+        dets = eng.decode(out_sizes)
+        results = []
+        for d, osz in zip(dets, out_sizes):
+            r = Instances(osz)
+            r.pred_boxes = Boxes(d["pred_boxes"])
+            r.scores = d["scores"]
+            r.pred_classes = d["pred_classes"]
+            r.locations = d["locations"]
+            r.fpn_levels = d["fpn_levels"]
+            results.append({"instances": r})
+        return results
+
+
+def build_model(cfg, dtype: Optional[str] = None) -> nn.Module:
+    """d2go runner.build_model equivalent for this path: META_ARCH_REGISTRY lookup by yaml name."""
+    return META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg, dtype=dtype)

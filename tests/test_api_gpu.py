@@ -1,0 +1,135 @@
+"""GPU tests of the reference-API mirror: MetaFCOSRunner episode flow, model(run_type=...) contract,
+SylphPredictor with on-disk class codes -- against the CPU oracle (fp32 mode)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    from sylph_amd.runner import MetaFCOSRunner, create_cfg
+    r = MetaFCOSRunner()
+    return r, create_cfg(r.get_default_cfg(), "sylph://COCO-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from oracle import weights as W
+    return W.synthetic_state_dict(0, depth=50)
+
+
+@pytest.fixture(scope="module")
+def model(sd):
+    runner, cfg = _cfg()
+    m = runner.build_model(cfg, dtype="f32")
+    m.load_state_dict(sd)
+    m.eval()
+    return m
+
+
+class _Collect:
+    def reset(self):
+        self.out = []
+
+    def process(self, inputs, outputs):
+        for i, o in zip(inputs, outputs):
+            self.out.append((i["image_id"], o["instances"]))
+
+    def evaluate(self):
+        return {"n": len(self.out)}
+
+
+def test_runner_episode_matches_oracle(model, sd):
+    from oracle import codegen as CG, episode as E
+    from sylph_amd.data import SyntheticQueryLoader, SyntheticSupportSetLoader
+    runner, cfg = _cfg()
+    sup = SyntheticSupportSetLoader(3, 2, 128, 160, seed=3)
+    qry = SyntheticQueryLoader(4, 120, 152, batch_size=2, seed=4)
+    ev = _Collect()
+    res, codes = runner._do_test_meta_learning(cfg, model, sup, qry, ev, num_classes=3)
+    assert res == {"n": 4} and codes["cls_conv"].shape == (3, 256, 1, 1) and codes["cls_bias"].shape == (3,)
+    # oracle: same support items -> codes
+    recs = []
+    for item in sup:
+        it = item[0]
+        imgs = [r["image"].cpu() for r in it["support_set"]]
+        boxes = torch.cat([r["instances"].gt_boxes.tensor for r in it["support_set"]])
+        recs.append({"support_set_target": it["support_set_target"], "class_name": it["class_name"],
+                     "class_code": E.forward_class_code(imgs, boxes, sd)})
+    ref = E.format_class_codes_shared(CG.forward_normalize_code(recs, sd))
+    np.testing.assert_allclose(codes["cls_conv"].cpu().numpy(), ref["cls_conv"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(codes["cls_bias"].cpu().numpy(), ref["cls_bias"].numpy(), atol=1e-3)
+    # queries with boosted codes so detections exist; same codes on both sides
+    boosted = {"cls_conv": ref["cls_conv"] * 3.0, "cls_bias": ref["cls_bias"]}
+    for batch in qry:
+        got = model(batch, class_code={k: v.cuda() for k, v in boosted.items()}, run_type="meta_learn_test_instance")
+        want = E.forward_instances([b["image"].cpu() for b in batch], boosted, sd)
+        for g, w in zip(got, want):
+            inst = g["instances"]
+            assert inst.image_size == (120, 152) and len(inst) == w["scores"].numel() and len(inst) > 0
+            np.testing.assert_array_equal(inst.pred_classes.cpu().numpy(), w["pred_classes"].numpy())
+            np.testing.assert_array_equal(inst.fpn_levels.cpu().numpy(), w["fpn_levels"].numpy())
+            np.testing.assert_array_equal(inst.locations.cpu().numpy(), w["locations"].numpy())
+            np.testing.assert_allclose(inst.scores.cpu().numpy(), w["scores"].numpy(), atol=1e-3)
+            np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), w["pred_boxes"].numpy(), atol=2e-2, rtol=1e-3)
+
+
+def test_model_contract_errors(model):
+    from sylph_amd.structures import Boxes, Instances
+    empty = Instances((64, 64))
+    empty.gt_boxes = Boxes(torch.zeros(0, 4))
+    empty.gt_classes = torch.zeros(0, dtype=torch.long)
+    item = [{"support_set": [{"image": torch.zeros(3, 64, 64), "instances": empty}],
+             "support_set_target": torch.tensor(0), "class_name": "x"}]
+    with pytest.raises(ValueError):
+        model(item, run_type="meta_learn_test_support")
+    with pytest.raises(AssertionError):
+        model([{"image": torch.zeros(3, 64, 64)}], class_code={"cls_conv": torch.zeros(2, 256), "cls_bias": None},
+              run_type="meta_learn_test_instance")
+    assert model.device.type == "cuda"
+
+
+def test_support_output_shapes_like_reference_test(model):
+    """tests/code_generator_code_generator_test.py:96-102 of the reference: cls_conv (1, OUT, k, k), cls_bias (1,1,1,1)."""
+    from sylph_amd.data import SyntheticSupportSetLoader
+    item = next(iter(SyntheticSupportSetLoader(1, 2, 96, 128, seed=1)))
+    code = model(item, run_type="meta_learn_test_support")
+    assert tuple(code["cls_conv"].shape) == (1, 256, 1, 1) and tuple(code["cls_bias"].shape) == (1, 1, 1, 1)
+    codes = [{"support_set_target": torch.tensor(i), "class_name": str(i),
+              "class_code": {"cls_conv": torch.rand(1, 256, 1, 1), "cls_bias": torch.rand(1, 1, 1, 1)}} for i in range(3)]
+    from sylph_amd.evaluation import inference_normalization
+    out = inference_normalization(model, codes)
+    assert isinstance(out, list) and len(out) == 3 and tuple(out[0]["class_code"]["cls_bias"].shape) == (1,)
+
+
+def test_predictor_roundtrip(sd, tmp_path, model):
+    from oracle import episode as E
+    from sylph_amd.data import SyntheticSupportSetLoader
+    from sylph_amd.evaluation import inference_normalization, inference_on_support_set_dataset
+    from sylph_amd.predictor import SylphPredictor, resize_image, resize_shortest_edge_shape
+    ckpt = str(tmp_path / "model_final.pth")
+    torch.save({"model": sd}, ckpt)
+    code_dir = str(tmp_path / "codes" / "synthetic_all" / "0")
+    sub = inference_on_support_set_dataset(model, SyntheticSupportSetLoader(2, 1, 128, 160, seed=5), output_dir=None)
+    sub = inference_normalization(model, sub)
+    os.makedirs(code_dir)
+    for c in sub:
+        c["class_code"] = {k: v.cpu() for k, v in c["class_code"].items()}
+        c["class_code"]["cls_conv"] = c["class_code"]["cls_conv"] * 3.0
+        torch.save(c, os.path.join(code_dir, f"{c['class_name']}.pth"))
+    pred = SylphPredictor("sylph://COCO-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml", ckpt, str(tmp_path / "codes"),
+                          test_dataset_names={"all": "synthetic_all"}, dtype="f32")
+    pred.min_size, pred.max_size = 96, 160   # keep the test image small
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, size=(90, 130, 3), dtype=np.uint8)
+    out = pred._call_few_shot(img, pred.class_codes["all"])["instances"]
+    nh, nw = resize_shortest_edge_shape(90, 130, 96, 160)
+    x = torch.as_tensor(resize_image(img, nh, nw).astype("float32").transpose(2, 0, 1))
+    codes = {k: v.cpu() for k, v in pred.class_codes["all"].items()}
+    want = E.forward_instances([x], codes, sd, out_sizes=[(90, 130)])[0]
+    assert out.image_size == (90, 130) and len(out) == want["scores"].numel() and len(out) > 0
+    np.testing.assert_allclose(out.scores.cpu().numpy(), want["scores"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), want["pred_boxes"].numpy(), atol=2e-2, rtol=1e-3)

@@ -1,0 +1,217 @@
+"""CPU-only tests: config surface, C-ABI symbol export, host logic of the API mirror, class-code
+gather/reduce over gloo (world_size 2).  No GPU compute."""
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from sylph_amd import config as C
+from sylph_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CONFIGS = "/root/reference/configs"
+
+
+# ------------------------------------------------------------------------------------ config
+def test_default_cfg_has_reference_keys():
+    cfg = C.get_default_cfg()
+    assert cfg.MODEL.FCOS.INFERENCE_TH_TEST == 0.05 and cfg.MODEL.FCOS.PRE_NMS_TOPK_TEST == 1000
+    assert cfg.MODEL.FCOS.NMS_TH == 0.6 and cfg.MODEL.FCOS.POST_NMS_TOPK_TEST == 100
+    assert cfg.MODEL.FCOS.FPN_STRIDES == [8, 16, 32, 64, 128] and cfg.MODEL.FCOS.BOX_QUALITY == ["ctrness"]
+    cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+    assert cg.NAME == "CodeGenerator" and cg.POST_NORM == "GN" and cg.ROI_BOX.POOLER_RESOLUTION == 7
+    assert cg.TRANSFORMER_ENCODER.HEADS == 8 and cg.HEAD.OUTPUT_DIM == 256
+    assert cfg.MODEL.TFA.USE_PRETRAINED_BASE_CLS_LOGITS is True and cfg.TEST.REPEAT_TEST == 1
+
+
+def test_sylph_prefix_and_base_chain_own_yaml():
+    cfg = C.get_default_cfg()
+    cfg.merge_from_file("sylph://COCO-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml")
+    assert cfg.MODEL.META_ARCHITECTURE == "MetaOneStageDetector"
+    assert cfg.MODEL.PROPOSAL_GENERATOR.NAME == "MetaFCOS"          # overrides the _BASE_ value "FCOS"
+    assert cfg.MODEL.FCOS.NUM_CLASSES == 60 and cfg.MODEL.RESNETS.DEPTH == 50
+    assert cfg.MODEL.META_LEARN.CODE_GENERATOR.TOWER_LAYERS == [["GN", "ReLU"], ["GN", "ReLU"]]
+    cfg.merge_from_list(["MODEL.RESNETS.DEPTH", "101", "MODEL.FCOS.INFERENCE_TH_TEST", 0.1])
+    assert cfg.MODEL.RESNETS.DEPTH == 101 and cfg.MODEL.FCOS.INFERENCE_TH_TEST == 0.1
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.MODEL.DEVICE = "cpu"
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.MODEL.DEVICE = "cpu"
+    assert cfg.MODEL.DEVICE == "cuda"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference configs not present on this box")
+@pytest.mark.parametrize("rel", ["COCO-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml",
+                                 "LVISv1-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml",
+                                 "LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml"])
+def test_reference_yamls_load_unchanged(rel, monkeypatch):
+    monkeypatch.setenv("SYLPH_CONFIG_ROOT", REF_CONFIGS)
+    cfg = C.get_default_cfg()
+    cfg.merge_from_file("sylph://" + rel)
+    assert cfg.MODEL.META_LEARN.EPISODIC_LEARNING is True
+    assert isinstance(cfg.SOLVER.STEPS, tuple)                      # unknown keys tolerated, tuples parsed
+    assert cfg.D2GO_DATA.MAPPER.NAME == "MetalearnDatasetMapper"
+    if "LVIS" in rel:
+        assert cfg.MODEL.FCOS.POST_NMS_TOPK_TEST == 300
+
+
+# ------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from sylph_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "sylph_hip.h")).read()
+    declared = set(re.findall(r"\b(sylph_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.PROTOTYPES.keys()), declared ^ set(_lib.PROTOTYPES.keys())
+    L = _lib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_config_struct_mapping_and_no_cpu_fallback():
+    from sylph_amd import _lib
+    from sylph_amd.engine import Engine, config_from_cfg
+    cfg = C.get_default_cfg()
+    cfg.merge_from_file("sylph://LVISv1-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml")
+    sc = config_from_cfg(cfg)
+    assert sc.post_nms_topk == 300 and sc.cg_bias_l2_norm == 1 and sc.cg_tower_layers == 2
+    assert abs(sc.pre_nms_thresh - 0.05) < 1e-7 and list(sc.strides)[:5] == [8, 16, 32, 64, 128]
+    cfg.MODEL.FCOS.NORM = "BN"
+    with pytest.raises(NotImplementedError):
+        config_from_cfg(cfg)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            Engine(C.get_default_cfg())
+
+
+# ------------------------------------------------------------------------------------ host logic
+def test_inference_shard_is_contiguous_ceil_blocks():
+    assert [D.inference_shard(866, r, 8) for r in range(8)][0] == (0, 109)
+    spans = [D.inference_shard(866, r, 8) for r in range(8)]
+    assert spans[-1] == (763, 866) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert D.inference_shard(5, 7, 8) == (5, 5) and D.inference_shard(0, 0, 4) == (0, 0)
+
+
+def test_resize_shortest_edge_shape():
+    from sylph_amd.predictor import resize_shortest_edge_shape
+    assert resize_shortest_edge_shape(480, 640, 800, 1333) == (800, 1067)
+    assert resize_shortest_edge_shape(400, 1000, 800, 1333) == (533, 1333)
+    assert resize_shortest_edge_shape(800, 1333, 800, 1333) == (800, 1333)
+
+
+def test_structures():
+    from sylph_amd.structures import Boxes, Instances
+    b = Boxes(torch.tensor([[0., 0., 10., 5.], [3., 3., 3., 9.]]))
+    assert b.area().tolist() == [50.0, 0.0] and b.nonempty().tolist() == [True, False]
+    i = Instances((20, 30), pred_boxes=b, scores=torch.tensor([0.9, 0.1]))
+    assert len(i) == 2 and len(i[i.scores > 0.5]) == 1 and i.image_size == (20, 30)
+    with pytest.raises(AssertionError):
+        i.pred_classes = torch.tensor([1])
+    j = Instances.cat([i, i])
+    assert len(j) == 4 and isinstance(j.pred_boxes, Boxes)
+
+
+def _chunks(g):
+    chunks = []
+    for i in range(5):
+        cc = {k: torch.as_tensor(g[f"chunk{i}_{k}"]) for k in ("cls_conv", "cls_bias")}
+        cc["acc_weight"] = float(g[f"chunk{i}_acc_weight"])
+        chunks.append({"support_set_target": int(g[f"chunk{i}_cid"]), "class_name": f"k{int(g[f'chunk{i}_cid'])}",
+                       "class_code": cc})
+    return chunks
+
+
+def test_reduce_class_code_matches_reference_golden(golden_dir):
+    from sylph_amd.runner import MetaFCOSRunner
+    g = np.load(os.path.join(golden_dir, "g5_reduce_condblock.npz"))
+    red = MetaFCOSRunner._gather_class_code(_chunks(g), reduce=True)
+    assert [r["support_set_target"] for r in red] == [0, 1]
+    for r in red:
+        cid = r["support_set_target"]
+        assert "acc_weight" not in r["class_code"]
+        np.testing.assert_allclose(r["class_code"]["cls_conv"].numpy(), g[f"reduced{cid}_cls_conv"], atol=1e-6)
+        np.testing.assert_allclose(r["class_code"]["cls_bias"].numpy(), g[f"reduced{cid}_cls_bias"], atol=1e-6)
+
+
+def test_format_class_codes_matches_reference_golden(golden_dir):
+    from sylph_amd.evaluation import format_class_codes_shared
+    g = np.load(os.path.join(golden_dir, "g3_codegen.npz"))
+    codes = [{"support_set_target": torch.tensor(i), "class_name": str(i),
+              "class_code": {"cls_conv": torch.from_numpy(g[f"coco_norm{i}_cls_conv"]),
+                             "cls_bias": torch.from_numpy(g[f"coco_norm{i}_cls_bias"])}} for i in range(3)]
+    fm = format_class_codes_shared([codes[2], codes[0], codes[1]], "cpu")
+    np.testing.assert_array_equal(fm["cls_conv"].numpy(), g["coco_fmt_cls_conv"])
+    np.testing.assert_array_equal(fm["cls_bias"].numpy(), g["coco_fmt_cls_bias"])
+
+
+def test_model_dispatch_errors_without_gpu():
+    """run_type dispatch / error types of MetaOneStageDetector.forward (meta_one_stage_detector.py:425-445)
+    are host logic; exercised on a stub that skips Engine construction."""
+    from sylph_amd.modeling import MetaOneStageDetector
+    m = MetaOneStageDetector.__new__(MetaOneStageDetector)
+    torch.nn.Module.__init__(m)
+    m.episodic_learning = True
+    m.eval()
+    with pytest.raises(NotImplementedError, match="not support this forward type"):
+        m([], run_type="bogus")
+    with pytest.raises(NotImplementedError):
+        m([], run_type=None)
+    m.train()
+    with pytest.raises(NotImplementedError, match="training is out of scope"):
+        m([], run_type="meta_learn_test_instance")
+    m.eval()
+    with pytest.raises(AssertionError, match="batched_inputs has length"):
+        m([{"support_set": []}, {"support_set": []}], run_type="meta_learn_test_support")
+
+
+# ------------------------------------------------------------------------------------ gloo, world 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, golden_dir, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sylph_amd.runner import MetaFCOSRunner
+        g = np.load(os.path.join(golden_dir, "g5_reduce_condblock.npz"))
+        chunks = _chunks(g)
+        mine = chunks[:2] if rank == 0 else chunks[2:]           # uneven: 2 + 3 chunks, class 0 split across ranks
+        gathered = MetaFCOSRunner._gather_class_code(mine)
+        reduced = MetaFCOSRunner._gather_class_code(mine, reduce=True)
+        # dense-block gather with an empty rank
+        local = D.pack_codes(torch.randn(3, 256), torch.randn(3), [4, 5, 6]) if rank == 1 else torch.zeros(0, D.ROW)
+        rows = D.gather_packed_codes(local)
+        if rank == 0:
+            torch.save({"gathered": gathered, "reduced": reduced, "rows": rows}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import episode as E
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), golden_dir, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=False)
+    g = np.load(os.path.join(golden_dir, "g5_reduce_condblock.npz"))
+    chunks = _chunks(g)
+    want = E.gather_class_code([chunks[:2], chunks[2:]])
+    assert [c["support_set_target"] for c in res["gathered"]] == [c["support_set_target"] for c in want]
+    assert [c["class_name"] for c in res["gathered"]] == [c["class_name"] for c in want]
+    for a, b in zip(res["gathered"], want):
+        np.testing.assert_array_equal(a["class_code"]["cls_conv"].numpy(), b["class_code"]["cls_conv"].numpy())
+        assert abs(a["class_code"]["acc_weight"] - b["class_code"]["acc_weight"]) < 1e-6
+    for r in res["reduced"]:
+        cid = r["support_set_target"]
+        np.testing.assert_allclose(r["class_code"]["cls_conv"].numpy(), g[f"reduced{cid}_cls_conv"], atol=1e-6)
+    assert res["rows"].shape == (3, D.ROW) and res["rows"][:, D.F_CID].tolist() == [4.0, 5.0, 6.0]
