@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="query images per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="query images per GPU per step")
     ap.add_argument("--ways", type=int, default=5)
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--height", type=int, default=800)
@@ -164,7 +164,7 @@ def main():
             "kernel": "conv_igemm_kernel (implicit-GEMM MFMA conv, all launches of the timed region)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-            "traffic": None,
+            "traffic": pmc_traffic_per_launch(B, launches // max(args.steps, 1)),
             "launches": launches, "avg_launch_us": round(conv_s / launches * 1e6, 2),
             "algorithmic_gflop_per_launch": round(alg_flops / launches / 1e9, 3),
             "gflop_counted_by_library_per_image": round(prof["conv_flops"] / images_timed / 1e9, 2),
@@ -189,6 +189,18 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic_per_launch(batch, launches_per_step):
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (separate runs of this same
+    command: FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; tools/rocpd_pmc.py).
+    Scaled from the profiled batch to this run's batch (traffic is per image); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")
+    if not os.path.exists(path) or launches_per_step <= 0:
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return round(d["hbm_bytes_per_image"] * batch / launches_per_step)
 
 
 def cpu_baseline(sd, queries, cls_conv, cls_bias, n_images):

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""HBM traffic of the conv kernel from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; rocpd dbs).
+
+    python tools/rocpd_pmc.py <fetch.db> <write.db> <batch> [out.json]
+
+Sums the counters over the conv_igemm_kernel launches of the LAST query step (from the last
+preprocess_kernel dispatch on).  Units/corrections as MI355X_MICROARCH.md prescribes: the counters are
+KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
+used as is (checked here against preprocess_kernel, whose write volume is known exactly)."""
+import json
+import sqlite3
+import sys
+
+
+def last_step(dbfile, counter):
+    db = sqlite3.connect(dbfile)
+    rows = db.execute("select kernel_name, value, start from counters_collection where counter_name=? order by start",
+                      (counter,)).fetchall()
+    idx = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]][-1]
+    step = rows[idx:]
+    conv = [r for r in step if "conv_igemm_kernel" in r[0]]
+    pre = step[0][1]
+    return sum(r[1] for r in conv) * 1024.0, len(conv), pre * 1024.0
+
+
+fetch, n1, pre_f = last_step(sys.argv[1], "FETCH_SIZE")
+write, n2, pre_w = last_step(sys.argv[2], "WRITE_SIZE")
+B = int(sys.argv[3])
+assert n1 == n2, (n1, n2)
+out = {
+    "batch": B, "conv_launches_per_step": n1,
+    "fetch_bytes_raw_per_step": fetch, "fetch_bytes_corrected_per_step": 2.0 * fetch, "write_bytes_per_step": write,
+    "hbm_bytes_per_image": (2.0 * fetch + write) / B,
+    "hbm_bytes_per_launch": (2.0 * fetch + write) / n1,
+    "calibration": {"preprocess_write_bytes": pre_w, "preprocess_write_expected": B * 800 * 1344 * 4 * 2,
+                    "preprocess_fetch_bytes_raw": pre_f, "preprocess_fetch_expected": B * 3 * 800 * 1333 * 4},
+    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncorrected",
+}
+print(json.dumps(out, indent=1))
+if len(sys.argv) > 4:
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
