@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--code-scale", type=float, default=3.0,
                     help="multiplier on the normalised class codes so the random-weight detector fires (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket conv launches with HIP events (roofline fields become 0)")
     ap.add_argument("--cpu-images", type=int, default=3)
     args = ap.parse_args()
 
@@ -132,7 +134,7 @@ def main():
 
     for _ in range(args.warmup):
         dets = step()
-    eng.profile_enable(True)
+    eng.profile_enable(not args.no_kernel_events)
     eng.profile_read()
     if world > 1:
         dist.barrier()

@@ -134,6 +134,11 @@ int64_t sylph_device_bytes(sylph_ctx* ctx);
  * synchronises the stream and returns the summed kernel time (ms), the algorithmic FLOPs
  * (2*M*N*K of the logical problem) and the number of launches since the previous read. */
 int sylph_profile_enable(sylph_ctx* ctx, int on);
+/* Kernel micro-benchmark (tuning aid): time `iters` back-to-back launches of one conv layer
+ * (B images of HxW, Cin->Cout, KxK, random bf16/fp32 operands) with HIP events; ms per launch and the
+ * algorithmic FLOPs of one launch are returned. */
+int sylph_bench_conv(sylph_ctx* ctx, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int has_res,
+                     int relu, int with_gn, int iters, float* ms_out, double* flops_out);
 int sylph_profile_read(sylph_ctx* ctx, double* conv_ms, double* conv_flops, int64_t* conv_launches);
 
 #ifdef __cplusplus

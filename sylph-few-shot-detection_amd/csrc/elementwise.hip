@@ -313,6 +313,26 @@ int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg
 }
 
 // ------------------------------------------------------------------------------------------------
+// pseudo-random fill in [-1, 1) (kernel micro-benchmarks: random operands, never zeros -- DVFS)
+template <typename T>
+__global__ void fill_random_kernel(T* __restrict__ p, size_t n, unsigned seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  p[i] = Cvt<T>::from_f((float)(h & 0xffffff) * (2.0f / 16777216.0f) - 1.0f);
+}
+
+int launch_fill_random(DType dt, void* p, size_t n, unsigned seed, hipStream_t s) {
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(fill_random_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)p, n, seed);
+  else
+    hipLaunchKernelGGL(fill_random_kernel<float>, grid, block, 0, s, (float*)p, n, seed);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // layout conversion (API boundary + tests): NCHW fp32 <-> position-major rows
 template <typename T>
 __global__ void import_nchw_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int HW, int row0,

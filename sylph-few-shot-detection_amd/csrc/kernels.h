@@ -68,6 +68,7 @@ int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int ma
 int launch_gn_apply_partials(DType dt, void* x, int ld, const GnSeg* segs_dev, int nseg, int max_rows,
                              const float* partial, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s);
+int launch_fill_random(DType dt, void* p, size_t n, unsigned seed, hipStream_t s);
 struct CopySeg { int src_row0, dst_row0, nrows; };
 int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg* segs_dev, int nseg, int max_rows,
                      hipStream_t s);

@@ -1136,6 +1136,54 @@ int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const fl
 
 int64_t sylph_device_bytes(sylph_ctx* c) { return c->bytes; }
 
+int sylph_bench_conv(sylph_ctx* c, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int has_res,
+                     int relu, int with_gn, int iters, float* ms_out, double* flops_out) {
+  HIPCHK(hipSetDevice(c->device));
+  const int bk = c->dt == DT_BF16 ? 64 : 32;
+  if (Cin % bk != 0) return fail("sylph_bench_conv: Cin must be a multiple of " + std::to_string(bk));
+  const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+  sylph_ctx tmp;
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
+  HostTensor hw;
+  hw.shape = {Cout, Cin, K, K};
+  hw.data.resize((size_t)Cout * Cin * K * K);
+  unsigned st = 12345u;
+  const float wsc = 1.0f / sqrtf((float)(Cin * K * K));
+  for (auto& v : hw.data) { st = st * 1664525u + 1013904223u; v = ((float)(st >> 8) * (2.0f / 16777216.0f) - 1.0f) * wsc; }
+  ConvLayer L;
+  RET(pack_conv(&tmp, {&hw}, &L));
+  RET(upload_vec(&tmp, &L.scale, std::vector<float>((size_t)Cout, 1.0f), L.Cout_pad));
+  RET(upload_vec(&tmp, &L.shift, std::vector<float>((size_t)Cout, 0.1f), L.Cout_pad));
+  void *xin, *yout, *res = nullptr;
+  const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Ho * Wo * Cout;
+  RET(tmp.dalloc(&xin, nin * tmp.esz()));
+  RET(tmp.dalloc(&yout, nout * tmp.esz()));
+  KCHK(launch_fill_random(c->dt, xin, nin, 1u, c->stream), "fill");
+  ConvOpts o; o.stride = stride; o.pad = pad; o.relu_nch = relu ? (1 << 30) : 0;
+  if (has_res) {
+    RET(tmp.dalloc(&res, nout * tmp.esz()));
+    KCHK(launch_fill_random(c->dt, res, nout, 2u, c->stream), "fill");
+    o.res = res; o.res_ld = Cout; o.res_mode = 1;
+  }
+  o.want_gn = with_gn;
+  std::vector<OpFn> ops;
+  RET(add_conv(&tmp, ops, L, xin, Cin, yout, Cout, image_segs(B, H, W, Ho, Wo), o));
+  for (int i = 0; i < 2; ++i) RET(run_ops(c, ops, "bench_conv"));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < iters; ++i) RET(run_ops(c, ops, "bench_conv"));
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms_out) *ms_out = ms / (float)iters;
+  if (flops_out) *flops_out = 2.0 * (double)B * Ho * Wo * Cout * K * K * Cin;
+  return 0;
+}
+
 int sylph_profile_enable(sylph_ctx* c, int on) {
   c->prof = on != 0;
   return 0;

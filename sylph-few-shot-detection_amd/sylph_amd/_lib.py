@@ -57,6 +57,7 @@ PROTOTYPES = {
     "sylph_group_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "sylph_device_bytes": (c_int64, [c_void_p]),
     "sylph_profile_enable": (c_int, [c_void_p, c_int]),
+    "sylph_bench_conv": (c_int, [c_void_p] + [c_int] * 12 + [POINTER(c_float), POINTER(ctypes.c_double)]),
     "sylph_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 

@@ -293,6 +293,14 @@ class Engine:
     def device_bytes(self) -> int:
         return int(self.L.sylph_device_bytes(self._ctx))
 
+    def bench_conv(self, B, H, W, Cin, Cout, K, stride=1, pad=0, res=False, relu=True, gn=False, iters=10):
+        """Kernel micro-benchmark: (ms per launch, TFLOP/s) of one conv layer on random operands."""
+        self._stream()
+        ms, fl = ctypes.c_float(0), ctypes.c_double(0)
+        check(self.L.sylph_bench_conv(self._ctx, B, H, W, Cin, Cout, K, stride, pad, int(res), int(relu), int(gn), iters,
+                                      ctypes.byref(ms), ctypes.byref(fl)), "bench_conv")
+        return ms.value, fl.value / (ms.value * 1e-3) / 1e12
+
     def profile_enable(self, on: bool = True):
         check(self.L.sylph_profile_enable(self._ctx, int(on)), "profile_enable")
 
