@@ -87,7 +87,7 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 // ---- launcher prototypes (one per translation unit) -----------------------------------------
 // conv_igemm.hip
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);
-void conv_pick_tile(int rows_total, int cout, int* BM, int* BN);
+void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 
 }  // namespace sylph

@@ -329,7 +329,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   long rows = 0;
   for (auto& s : segs) rows += (long)s.out_H * s.out_W;
   int BM, BN;
-  conv_pick_tile((int)rows, L.Cout_pad, &BM, &BN);
+  conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN);
   if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
   Geom g;
   RET(make_geom(c, segs, BM, &g));
@@ -604,7 +604,7 @@ static int build_head(sylph_ctx* c, Plan* P) {
   {
     Geom g;
     int BM, BN;
-    conv_pick_tile((int)rows, 128, &BM, &BN);
+    conv_pick_tile((int)rows, 128, 9, &BM, &BN);  // geometry for BN in {64,128}; BM from the 128-wide rule
     RET(make_geom(c, segs, BM, &g));
     P->head_segs = g.segs; P->head_tiles = g.tiles; P->head_mtiles = g.n_mtiles; P->head_BM = BM;
     Geom g32;
