@@ -150,3 +150,54 @@ def synthetic_codes(n: int, c: int = 256, seed: int = 3, scale: float = 1.0) -> 
     w = torch.randn(n, c, 1, 1, generator=g)
     w = w / w.flatten(1).norm(dim=1).view(n, 1, 1, 1) * scale
     return {"cls_conv": w, "cls_bias": torch.full((n,), -math.log(99.0)) + 0.1 * torch.randn(n, generator=g)}
+
+
+def roi_encoder_state_dict(seed: int = 4, c: int = 256, inter: int = 64, fc_dim: int = 256, head_fc: int = 512,
+                           layers: int = 2, tok_convs: int = 2, tok_fcs: int = 2) -> Dict[str, torch.Tensor]:
+    """Seeded weights in the key layout of the reference ROIEncoder module
+    (sylph/modeling/code_generator/roi_encoder.py:206-281, utils.py:70-141)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    p = "code_generator"
+
+    def lin(name, o, i, std=None):
+        sd[f"{name}.weight"] = torch.randn(o, i, generator=g) * (std if std is not None else math.sqrt(1.0 / i))
+        sd[f"{name}.bias"] = torch.randn(o, generator=g) * 0.1
+
+    def gn(name, ch):
+        sd[f"{name}.weight"] = 1.0 + 0.1 * torch.randn(ch, generator=g)
+        sd[f"{name}.bias"] = 0.1 * torch.randn(ch, generator=g)
+
+    sd[f"{p}.box_pooler.conv.0.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
+    sd[f"{p}.box_pooler.conv.0.bias"] = torch.randn(c, generator=g) * 0.1
+    gn(f"{p}.box_pooler.conv.1", c)
+    cam = f"{p}.box_pooler.context_attention_module"
+    for branch, idx in (("local_att", (0, 1, 3, 4)), ("global_att", (1, 2, 4, 5))):
+        sd[f"{cam}.{branch}.{idx[0]}.weight"] = _conv(g, inter, c, 1, std=math.sqrt(1.0 / c))
+        sd[f"{cam}.{branch}.{idx[0]}.bias"] = torch.randn(inter, generator=g) * 0.1
+        gn(f"{cam}.{branch}.{idx[1]}", inter)
+        sd[f"{cam}.{branch}.{idx[2]}.weight"] = _conv(g, c, inter, 1, std=math.sqrt(1.0 / inter))
+        sd[f"{cam}.{branch}.{idx[2]}.bias"] = torch.randn(c, generator=g) * 0.1
+        gn(f"{cam}.{branch}.{idx[3]}", c)
+    for k in range(tok_convs):
+        sd[f"{p}.tokenizer.conv{k + 1}.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
+        gn(f"{p}.tokenizer.conv{k + 1}.norm", c)
+    din = c * 49
+    for k in range(tok_fcs):
+        lin(f"{p}.tokenizer.fc{k + 1}", fc_dim, din, std=math.sqrt(2.0 / din))
+        din = fc_dim
+    for l in range(layers):
+        q = f"{p}.transformer_encoder.layers.{l}"
+        sd[f"{q}.self_attn.in_proj_weight"] = torch.randn(3 * fc_dim, fc_dim, generator=g) * math.sqrt(1.0 / fc_dim)
+        sd[f"{q}.self_attn.in_proj_bias"] = torch.randn(3 * fc_dim, generator=g) * 0.1
+        lin(f"{q}.self_attn.out_proj", fc_dim, fc_dim)
+        lin(f"{q}.linear1", 4 * fc_dim, fc_dim, std=math.sqrt(2.0 / fc_dim))
+        lin(f"{q}.linear2", fc_dim, 4 * fc_dim)
+        gn(f"{q}.norm1", fc_dim)
+        gn(f"{q}.norm2", fc_dim)
+    lin(f"{p}.weight_head.fc1", head_fc, fc_dim, std=math.sqrt(2.0 / fc_dim))
+    lin(f"{p}.weight_head.fc2", c, head_fc)
+    lin(f"{p}.bias_head.fc1", head_fc, fc_dim, std=math.sqrt(2.0 / fc_dim))
+    lin(f"{p}.bias_head.fc2", 1, head_fc)
+    sd["proposal_generator.fcos_head.cond_cls_logits.scales.0.scale"] = torch.tensor([0.8])
+    return sd

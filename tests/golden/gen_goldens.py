@@ -214,10 +214,50 @@ def gen_reduce_condblock():
     np.savez_compressed(os.path.join(HERE, "g5_reduce_condblock.npz"), **out)
 
 
+def gen_roi_encoder():
+    """ROIEncoder (LVIS ROI-encoder yaml dims) on seeded pyramids; S = EVAL_SHOT shots of one class."""
+    from sylph.modeling.code_generator.roi_encoder import ROIEncoder
+    from ref_shim import Boxes, Instances
+    out = {}
+    sd = W.roi_encoder_state_dict(seed=4)
+    out["weights_checksum"] = checksum(sd, "code_generator")
+    H, Wd = 192, 256
+    for S in (2, 5):
+        cfg = make_cfg(True)
+        cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+        cg.NAME = "ROIEncoder"
+        cg.TOKENIZER.NUM_CONV, cg.TOKENIZER.CONV_DIM, cg.TOKENIZER.NORM = 2, 256, "GN"
+        cg.TOKENIZER.NUM_FC, cg.TOKENIZER.FC_DIM = 2, 256
+        cg.TRANSFORMER_ENCODER.LAYERS, cg.TRANSFORMER_ENCODER.HEADS = 2, 8
+        cg.HEAD.NUM_FC, cg.HEAD.FC_DIM, cg.HEAD.OUTPUT_DIM = 2, 512, 256
+        cfg.MODEL.META_LEARN.EVAL_SHOT = S
+        enc = ROIEncoder(cfg, 256, 5, cfg.MODEL.FCOS.FPN_STRIDES).eval()
+        missing = load_prefixed(enc, sd, "code_generator")
+        assert not missing, missing
+        feats = feature_pyramid(S, H, Wd, seed=300 + S)
+        boxes = W.synthetic_boxes(S, H, Wd, seed=400 + S)
+        insts = []
+        for i in range(S):
+            it = Instances((H, Wd))
+            it.gt_boxes = Boxes(boxes[i:i + 1])
+            it.gt_classes = torch.tensor([7])
+            insts.append(it)
+        with torch.no_grad():
+            code = enc(feats, insts)
+        for l, f in enumerate(feats):
+            out[f"s{S}_feat{l}_q8"] = q8(f)
+        out[f"s{S}_boxes"] = boxes.numpy()
+        out[f"s{S}_cls_conv"] = code["cls_conv"].numpy()
+        out[f"s{S}_cls_bias"] = code["cls_bias"].numpy()
+        print("roi_encoder", S, code["cls_conv"].flatten()[:3], code["cls_bias"])
+    np.savez_compressed(os.path.join(HERE, "g7_roi_encoder.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     gen_head_decode()
     gen_codegen()
     gen_reduce_condblock()
+    gen_roi_encoder()
     print("done")

@@ -151,8 +151,8 @@ class ROIPooler(nn.Module):
         self.min_level = int(round(-math.log2(scales[0])))
         self.max_level = int(round(-math.log2(scales[-1])))
         self.canonical_box_size, self.canonical_level = canonical_box_size, canonical_level
-        self.level_poolers = nn.ModuleList()
         assert pooler_type == "ROIAlignV2" and sampling_ratio == 0
+        self.level_poolers = nn.ModuleList([_LevelROIAlign(self.output_size[0], sc) for sc in scales])
 
     def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]):
         from oracle.roi_align import roi_pooler
@@ -160,6 +160,35 @@ class ROIPooler(nn.Module):
         boxes = torch.cat([b.tensor for b in box_lists], dim=0)
         strides = [int(round(1.0 / s)) for s in self.scales]
         return roi_pooler([f.detach() for f in x], boxes, strides, self.output_size[0])
+
+
+class _LevelROIAlign(nn.Module):
+    """detectron2.layers.ROIAlign(aligned=True, sampling_ratio=0) on (K,5) rois, via the oracle restatement."""
+
+    def __init__(self, out_size, scale):
+        super().__init__()
+        self.out_size, self.scale = out_size, scale
+
+    def forward(self, x, rois):
+        from oracle.roi_align import roi_align_single
+        outs = [roi_align_single(x[int(r[0])].detach(), r[1:].tolist(), self.scale, self.out_size) for r in rois]
+        if not outs:
+            return x.new_zeros((0, x.shape[1], self.out_size, self.out_size))
+        return torch.stack(outs, dim=0)
+
+
+def convert_boxes_to_pooler_format(box_lists):
+    rows = []
+    for i, b in enumerate(box_lists):
+        t = b.tensor
+        rows.append(torch.cat([torch.full((len(t), 1), float(i)), t], dim=1))
+    return torch.cat(rows, dim=0)
+
+
+def assign_boxes_to_levels_shim(box_lists, min_level, max_level, canonical_box_size, canonical_level):
+    from oracle.roi_align import assign_boxes_to_levels
+    boxes = torch.cat([b.tensor for b in box_lists], dim=0)
+    return assign_boxes_to_levels(boxes, min_level, max_level, canonical_box_size, canonical_level)
 
 
 def ml_nms(boxlist, nms_thresh, max_proposals=-1, score_field="scores", label_field="labels"):
@@ -220,6 +249,32 @@ def _configurable(init_func=None, *, from_config=None):
     return wrap
 
 
+class Conv2dWrapper(nn.Conv2d):
+    """detectron2.layers.Conv2d: nn.Conv2d with optional ``norm`` and ``activation`` submodules."""
+
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = nn.functional.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def get_norm(norm, out_channels):
+    if norm is None or norm == "":
+        return None
+    assert norm == "GN", norm
+    return nn.GroupNorm(32, out_channels)
+
+
 def install():
     """Register stand-ins in sys.modules and put the reference on sys.path."""
     def mod(name, inert=False, **attrs):
@@ -244,13 +299,14 @@ def install():
     mod("detectron2.utils.file_io", PathManager=_PathManager)
     mod("detectron2.utils.comm", inert=True, get_world_size=lambda: 1)
     mod("detectron2.utils.logger", inert=True)
-    mod("detectron2.layers", inert=True, ShapeSpec=ShapeSpec, cat=cat, nonzero_tuple=nonzero_tuple)
+    mod("detectron2.layers", inert=True, ShapeSpec=ShapeSpec, cat=cat, nonzero_tuple=nonzero_tuple,
+        Conv2d=Conv2dWrapper, get_norm=get_norm)
     mod("detectron2.layers.batch_norm", inert=True)
     mod("detectron2.structures", inert=True, Boxes=Boxes, Instances=Instances)
     mod("detectron2.modeling", inert=True)
-    from oracle.roi_align import assign_boxes_to_levels
     mod("detectron2.modeling.poolers", inert=True, ROIPooler=ROIPooler,
-        assign_boxes_to_levels=assign_boxes_to_levels)
+        assign_boxes_to_levels=assign_boxes_to_levels_shim,
+        convert_boxes_to_pooler_format=convert_boxes_to_pooler_format)
     mod("detectron2.modeling.proposal_generator", inert=True)
     mod("detectron2.modeling.proposal_generator.build", PROPOSAL_GENERATOR_REGISTRY=Registry("PG"))
     mod("detectron2.config", inert=True, configurable=_configurable)
@@ -265,6 +321,8 @@ def install():
     mod("adet.utils.comm", inert=True, compute_locations=compute_locations)
     mod("fvcore", inert=True)
     mod("fvcore.nn", inert=True)
+    mod("fvcore.nn.weight_init", c2_msra_fill=lambda m: None, c2_xavier_fill=lambda m: None)
+    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
     mod("pycocotools", inert=True)
     mod("pycocotools.cocoeval", inert=True)
     mod("pycocotools.coco", inert=True)

@@ -131,3 +131,16 @@ def test_reduce_and_condblock_match_reference(golden_dir):
     for k in (1, 2):
         y = H.cond_conv_block(feat, torch.from_numpy(g[f"ccb{k}_w"]), torch.from_numpy(g[f"ccb{k}_b"]))
         np.testing.assert_allclose(y.numpy(), g[f"ccb{k}_y"], atol=TOL, rtol=TOL)
+
+
+@pytest.mark.parametrize("S", [2, 5])
+def test_roi_encoder_matches_reference(golden_dir, S):
+    """ROIEncoder code generator against the reference module's own output."""
+    from oracle import roi_encoder as R
+    g = _load(golden_dir, "g7_roi_encoder.npz")
+    sd = W.roi_encoder_state_dict(seed=4)
+    assert abs(_checksum(sd, "code_generator") - float(g["weights_checksum"])) < 1e-2
+    out = R.roi_encoder(_feats(g, f"s{S}_feat"), torch.from_numpy(g[f"s{S}_boxes"]), sd, num_shots=S)
+    assert out["cls_conv"].shape == (1, 256, 1, 1) and out["cls_bias"].shape == (1,)
+    np.testing.assert_allclose(out["cls_conv"].numpy(), g[f"s{S}_cls_conv"], atol=5e-5, rtol=5e-5)
+    np.testing.assert_allclose(out["cls_bias"].numpy(), g[f"s{S}_cls_bias"], atol=5e-5, rtol=5e-5)
