@@ -55,6 +55,13 @@ typedef struct sylph_config {
   int cg_use_weight_scale; /* CODE_GENERATOR.USE_WEIGHT_SCALE */
   float prior_prob;        /* MODEL.FCOS.PRIOR_PROB */
   int cand_cap;            /* per (image, level) candidate capacity of the decode scan (0 = default) */
+  /* ROIEncoder variant (sylph/runner/default_configs.py:149-167; LVIS ROI-Encoder yaml) */
+  int cg_type;             /* CODE_GENERATOR.NAME: 0 "CodeGenerator", 1 "ROIEncoder" */
+  int tok_num_conv;        /* TOKENIZER.NUM_CONV (conv3x3 + GN + ReLU, CONV_DIM 256, NORM "GN") */
+  int tok_num_fc;          /* TOKENIZER.NUM_FC (FC_DIM 256) */
+  int enc_layers;          /* TRANSFORMER_ENCODER.LAYERS */
+  int head_num_fc;         /* HEAD.NUM_FC */
+  int head_fc_dim;         /* HEAD.FC_DIM (OUTPUT_DIM 256) */
 } sylph_config;
 
 /* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */
@@ -110,7 +117,10 @@ int sylph_decode_nms(sylph_ctx* ctx, const int* out_heights, const int* out_widt
 /* CodeGenerator.forward / CodeGeneratorHead.forward_roi_align, eval branch
  * (sylph/modeling/code_generator/code_generator.py:924-1002): the current batch is the S support
  * images of ONE class; boxes_dev (S,4) fp32 XYXY (one gt box per image).  code_out_dev: 257 fp32 =
- * un-normalised cls_conv[256] ++ cls_bias[1]. */
+ * un-normalised cls_conv[256] ++ cls_bias[1].
+ * With cg_type 1 this is ROIEncoder.forward (sylph/modeling/code_generator/roi_encoder.py:146-204,
+ * S = EVAL_SHOT shots of one class): cls_conv[256] ++ cls_bias[1] (prior already added, no
+ * normalisation step exists for this variant). */
 int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
 
 /* CodeGeneratorHead.forward_normalize_code (code_generator.py:832-897): codes_dev (n,257) in place. */

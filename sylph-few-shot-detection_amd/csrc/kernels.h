@@ -92,4 +92,17 @@ int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_ou
 int launch_normalize_codes(float* codes, int ncodes, int C, const float* gn_gamma, const float* gn_beta, int post_norm,
                            int l2_norm, float conv_scale, float bias_scale, float bias_prior, hipStream_t s);
 
+// roi_encoder.hip
+struct MsCamWeights {  // fp32 device pointers: conv1x1 256->64, GN(32,64), conv1x1 64->256, GN(32,256); local / global
+  const float *l_w1, *l_b1, *l_g1, *l_be1, *l_w2, *l_b2, *l_g2, *l_be2;
+  const float *g_w1, *g_b1, *g_g1, *g_be1, *g_w2, *g_b2, *g_g2, *g_be2;
+};
+int launch_adaptive_context(DType dt, const void* feats, int ld, const LevelDesc* lv_dev, int nlevels, int S,
+                            int out_size, float* ctx, hipStream_t s);
+int launch_mscam(DType dt, const float* ctx, void* x, int S, const MsCamWeights& w, hipStream_t s);
+int launch_linear(int x_is_bf16, const void* x, int ldx, int S, const float* W, const float* b, int K, int O, float* y,
+                  int ldy, int relu, float add, hipStream_t s);
+int launch_add_layernorm(float* x, const float* r, int S, const float* gamma, const float* beta, hipStream_t s);
+int launch_mean_tokens(const float* x, int S, float* out, hipStream_t s);
+
 }  // namespace sylph

@@ -92,7 +92,17 @@ struct sylph_ctx {
   ConvLayer cg_cls, cg_bias;
   GNLayer cg_post;
   float cg_conv_scale = 1.f, cg_bias_scale = 1.f;
-  bool has_backbone = false, has_head = false, has_codegen = false;
+  // ROIEncoder variant
+  struct Lin { float* W = nullptr; float* b = nullptr; int K = 0, O = 0; };
+  struct EncLayer { Lin attn, l1, l2; GNLayer n1, n2; };
+  struct RoiEnc {
+    ConvLayer pool_conv; GNLayer pool_gn;
+    MsCamWeights cam;
+    std::vector<ConvLayer> tok_conv; std::vector<GNLayer> tok_gn;
+    std::vector<Lin> tok_fc, wh, bh;
+    std::vector<EncLayer> layers;
+  } re;
+  bool has_backbone = false, has_head = false, has_codegen = false, has_roienc = false;
   // plans
   std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
   Plan* cur = nullptr;
@@ -150,6 +160,7 @@ struct Plan {
   LevelDesc* lv_dev = nullptr;
   void *roi = nullptr, *cgA = nullptr, *cgB = nullptr;
   float *cg_conv_out = nullptr, *cg_bias_out = nullptr;
+  float *re_ctx = nullptr, *re_tok = nullptr, *re_tmp = nullptr, *re_hid = nullptr, *re_cls = nullptr, *re_h = nullptr;
   const float* cur_boxes = nullptr;
   float* cur_code_out = nullptr;
 };
@@ -244,6 +255,32 @@ static int make_gn(sylph_ctx* c, const std::string& name, GNLayer* G) {
   const HostTensor *g = find_w(c, name + ".weight"), *b = find_w(c, name + ".bias");
   if (!g || !b) return fail("missing weights for " + name);
   if (g->data.size() != 256) return fail("GroupNorm layers must have 256 channels: " + name);
+  RET(upload_vec(c, &G->gamma, g->data, 256));
+  RET(upload_vec(c, &G->beta, b->data, 256));
+  return 0;
+}
+
+static int upload_f32(sylph_ctx* c, const float** dev, const HostTensor* t, const std::string& what, size_t expect = 0) {
+  if (!t) return fail("missing weights for " + what);
+  if (expect && t->data.size() != expect) return fail("unexpected size for " + what);
+  void* d;
+  RET(upload(c, &d, t->data.data(), t->data.size() * 4));
+  *dev = (const float*)d;
+  return 0;
+}
+
+static int make_lin(sylph_ctx* c, const std::string& name, sylph_ctx::Lin* L) {
+  const HostTensor *w = find_w(c, name + ".weight"), *b = find_w(c, name + ".bias");
+  if (!w || !b || w->shape.size() != 2) return fail("missing weights for " + name);
+  L->O = (int)w->shape[0]; L->K = (int)w->shape[1];
+  RET(upload(c, (void**)&L->W, w->data.data(), w->data.size() * 4));
+  RET(upload(c, (void**)&L->b, b->data.data(), b->data.size() * 4));
+  return 0;
+}
+
+static int make_ln(sylph_ctx* c, const std::string& name, GNLayer* G) {
+  const HostTensor *g = find_w(c, name + ".weight"), *b = find_w(c, name + ".bias");
+  if (!g || !b || g->data.size() != 256) return fail("missing weights for " + name);
   RET(upload_vec(c, &G->gamma, g->data, 256));
   RET(upload_vec(c, &G->beta, b->data, 256));
   return 0;
@@ -710,6 +747,114 @@ static int build_support(sylph_ctx* c, Plan* P) {
   return 0;
 }
 
+static int build_support_roienc(sylph_ctx* c, Plan* P) {
+  if (P->support_built) return 0;
+  if (!c->has_roienc) return fail("ROIEncoder weights were not loaded");
+  RET(ensure_pyramid(c, P));
+  const size_t e = c->esz();
+  const int S = P->B, L = c->cfg.nlevels, npos = 49;
+  if (S > 16) return fail("ROIEncoder: at most 16 shots per class are supported");
+  std::vector<LevelDesc> lv;
+  for (int b = 0; b < S; ++b)
+    for (int l = 0; l < L; ++l)
+      lv.push_back(LevelDesc{b * P->Ltot + P->off[l], P->hl[l], P->wl[l], 1.0f / (float)c->cfg.strides[l]});
+  RET(upload(c, (void**)&P->lv_dev, lv.data(), lv.size() * sizeof(LevelDesc)));
+  RET(c->dalloc(&P->roi, (size_t)S * npos * 256 * e));
+  RET(c->dalloc(&P->cgA, (size_t)S * npos * 256 * e));
+  RET(c->dalloc(&P->cgB, (size_t)S * npos * 256 * e));
+  RET(c->dalloc((void**)&P->re_ctx, (size_t)S * npos * 256 * 4));
+  RET(c->dalloc((void**)&P->re_tok, (size_t)S * 256 * 4));
+  RET(c->dalloc((void**)&P->re_tmp, (size_t)S * 256 * 4));
+  int maxhid = 1024;
+  for (auto& l : c->re.layers) maxhid = l.l1.O > maxhid ? l.l1.O : maxhid;
+  RET(c->dalloc((void**)&P->re_hid, (size_t)S * maxhid * 4));
+  RET(c->dalloc((void**)&P->re_cls, 256 * 4));
+  RET(c->dalloc((void**)&P->re_h, (size_t)2 * (c->cfg.head_fc_dim > 256 ? c->cfg.head_fc_dim : 256) * 4));
+  const std::vector<SegDesc> segs = image_segs(S, 7, 7, 7, 7);
+  auto& ops = P->support_ops;
+  const DType dt = c->dt;
+  const int xbf = dt == DT_BF16 ? 1 : 0;
+  Plan* PP = P;
+  auto& R = c->re;
+  {
+    const void* F = P->F;
+    const LevelDesc* lvd = P->lv_dev;
+    void* roi = P->roi;
+    float* ctx = P->re_ctx;
+    ops.push_back([=](hipStream_t s) { return launch_roi_align(dt, F, 256, lvd, L, PP->cur_boxes, S, 7, roi, s); });
+    ops.push_back([=](hipStream_t s) { return launch_adaptive_context(dt, F, 256, lvd, L, S, 7, ctx, s); });
+  }
+  ConvOpts o; o.pad = 1;
+  RET(add_conv_gn(c, ops, R.pool_conv, P->roi, 256, P->cgA, segs, o, R.pool_gn, 1));
+  {
+    const float* ctx = P->re_ctx;
+    void* x = P->cgA;
+    const MsCamWeights w = R.cam;
+    ops.push_back([=](hipStream_t s) { return launch_mscam(dt, ctx, x, S, w, s); });
+  }
+  void* cur = P->cgA;
+  void* nxt = P->cgB;
+  for (size_t k = 0; k < R.tok_conv.size(); ++k) {
+    RET(add_conv_gn(c, ops, R.tok_conv[k], cur, 256, nxt, segs, o, R.tok_gn[k], 1));
+    std::swap(cur, nxt);
+  }
+  // tokenizer FC stack: first FC reads the (position-major) activations directly
+  float* tok = P->re_tok;
+  float* tmp = P->re_tmp;
+  float* hid = P->re_hid;
+  {
+    const sylph_ctx::Lin f0 = R.tok_fc[0];
+    const void* x = cur;
+    ops.push_back([=](hipStream_t s) { return launch_linear(xbf, x, npos * 256, S, f0.W, f0.b, f0.K, f0.O, tok, 256, 1, 0.f, s); });
+    float* a = tok;
+    float* b = tmp;
+    for (size_t k = 1; k < R.tok_fc.size(); ++k) {
+      const sylph_ctx::Lin f = R.tok_fc[k];
+      ops.push_back([=](hipStream_t s) { return launch_linear(0, a, 256, S, f.W, f.b, f.K, f.O, b, 256, 1, 0.f, s); });
+      std::swap(a, b);
+    }
+    tok = a;
+    tmp = b;
+  }
+  for (auto& l : R.layers) {
+    const sylph_ctx::Lin at = l.attn, l1 = l.l1, l2 = l.l2;
+    const GNLayer n1 = l.n1, n2 = l.n2;
+    float *x = tok, *t = tmp;
+    ops.push_back([=](hipStream_t s) { return launch_linear(0, x, 256, S, at.W, at.b, 256, 256, t, 256, 0, 0.f, s); });
+    ops.push_back([=](hipStream_t s) { return launch_add_layernorm(x, t, S, n1.gamma, n1.beta, s); });
+    ops.push_back([=](hipStream_t s) { return launch_linear(0, x, 256, S, l1.W, l1.b, l1.K, l1.O, hid, l1.O, 1, 0.f, s); });
+    ops.push_back([=](hipStream_t s) { return launch_linear(0, hid, l1.O, S, l2.W, l2.b, l2.K, l2.O, t, 256, 0, 0.f, s); });
+    ops.push_back([=](hipStream_t s) { return launch_add_layernorm(x, t, S, n2.gamma, n2.beta, s); });
+  }
+  {
+    float* cls = P->re_cls;
+    float* x = tok;
+    ops.push_back([=](hipStream_t s) { return launch_mean_tokens(x, S, cls, s); });
+    const float prior = -logf((1.f - c->cfg.prior_prob) / c->cfg.prior_prob);
+    for (int head = 0; head < 2; ++head) {
+      const std::vector<sylph_ctx::Lin>& fcs = head == 0 ? R.wh : R.bh;
+      const float* in = cls;
+      float* h0 = P->re_h + (size_t)head * (c->cfg.head_fc_dim > 256 ? c->cfg.head_fc_dim : 256);
+      for (size_t k = 0; k < fcs.size(); ++k) {
+        const sylph_ctx::Lin f = fcs[k];
+        const bool last = k + 1 == fcs.size();
+        const float add = (last && head == 1) ? prior : 0.f;
+        const int off = head == 0 ? 0 : 256;
+        if (last) {
+          ops.push_back([=](hipStream_t s) {
+            return launch_linear(0, in, f.K, 1, f.W, f.b, f.K, f.O, PP->cur_code_out + off, f.O, 0, add, s);
+          });
+        } else {
+          ops.push_back([=](hipStream_t s) { return launch_linear(0, in, f.K, 1, f.W, f.b, f.K, f.O, h0, f.O, 1, 0.f, s); });
+          in = h0;
+        }
+      }
+    }
+  }
+  P->support_built = true;
+  return 0;
+}
+
 static int run_ops(sylph_ctx* c, const std::vector<OpFn>& ops, const char* what) {
   for (size_t i = 0; i < ops.size(); ++i) {
     const int r = ops[i](c->stream);
@@ -734,6 +879,8 @@ void sylph_config_default(sylph_config* cfg) {
   cfg->thresh_with_ctr = 0; cfg->quality_mode = 0;
   cfg->cg_tower_layers = 2; cfg->cg_has_bias = 1; cfg->cg_bias_l2_norm = 0; cfg->cg_post_norm = 1;
   cfg->cg_conv_l2_norm = 1; cfg->cg_use_weight_scale = 1; cfg->prior_prob = 0.01f; cfg->cand_cap = 0;
+  cfg->cg_type = 0; cfg->tok_num_conv = 2; cfg->tok_num_fc = 2; cfg->enc_layers = 2; cfg->head_num_fc = 2;
+  cfg->head_fc_dim = 512;
 }
 
 const char* sylph_last_error(void) { return g_err.c_str(); }
@@ -852,7 +999,7 @@ int sylph_finalize_weights(sylph_ctx* c) {
     c->has_backbone = true;
   }
   const std::string hp = "proposal_generator.fcos_head";
-  if (has_prefix(c, hp)) {
+  if (has_prefix(c, hp + ".cls_tower") || has_prefix(c, hp + ".bbox_tower")) {
     c->cls_tower.resize(c->cfg.num_cls_convs); c->cls_gn.resize(c->cfg.num_cls_convs);
     c->box_tower.resize(c->cfg.num_box_convs); c->box_gn.resize(c->cfg.num_box_convs);
     for (int i = 0; i < c->cfg.num_cls_convs; ++i) {
@@ -897,6 +1044,94 @@ int sylph_finalize_weights(sylph_ctx* c) {
       c->cg_bias_scale = s->data[0];
     }
     c->has_codegen = true;
+  }
+  if (c->cfg.cg_type == 1 && has_prefix(c, "code_generator.box_pooler")) {
+    const std::string rp = "code_generator";
+    auto& R = c->re;
+    RET(make_conv_bias(c, {rp + ".box_pooler.conv.0"}, &R.pool_conv));
+    RET(make_gn(c, rp + ".box_pooler.conv.1", &R.pool_gn));
+    const std::string cam = rp + ".box_pooler.context_attention_module";
+    RET(upload_f32(c, &R.cam.l_w1, find_w(c, cam + ".local_att.0.weight"), cam, 64 * 256));
+    RET(upload_f32(c, &R.cam.l_b1, find_w(c, cam + ".local_att.0.bias"), cam, 64));
+    RET(upload_f32(c, &R.cam.l_g1, find_w(c, cam + ".local_att.1.weight"), cam, 64));
+    RET(upload_f32(c, &R.cam.l_be1, find_w(c, cam + ".local_att.1.bias"), cam, 64));
+    RET(upload_f32(c, &R.cam.l_w2, find_w(c, cam + ".local_att.3.weight"), cam, 256 * 64));
+    RET(upload_f32(c, &R.cam.l_b2, find_w(c, cam + ".local_att.3.bias"), cam, 256));
+    RET(upload_f32(c, &R.cam.l_g2, find_w(c, cam + ".local_att.4.weight"), cam, 256));
+    RET(upload_f32(c, &R.cam.l_be2, find_w(c, cam + ".local_att.4.bias"), cam, 256));
+    RET(upload_f32(c, &R.cam.g_w1, find_w(c, cam + ".global_att.1.weight"), cam, 64 * 256));
+    RET(upload_f32(c, &R.cam.g_b1, find_w(c, cam + ".global_att.1.bias"), cam, 64));
+    RET(upload_f32(c, &R.cam.g_g1, find_w(c, cam + ".global_att.2.weight"), cam, 64));
+    RET(upload_f32(c, &R.cam.g_be1, find_w(c, cam + ".global_att.2.bias"), cam, 64));
+    RET(upload_f32(c, &R.cam.g_w2, find_w(c, cam + ".global_att.4.weight"), cam, 256 * 64));
+    RET(upload_f32(c, &R.cam.g_b2, find_w(c, cam + ".global_att.4.bias"), cam, 256));
+    RET(upload_f32(c, &R.cam.g_g2, find_w(c, cam + ".global_att.5.weight"), cam, 256));
+    RET(upload_f32(c, &R.cam.g_be2, find_w(c, cam + ".global_att.5.bias"), cam, 256));
+    R.tok_conv.resize(c->cfg.tok_num_conv); R.tok_gn.resize(c->cfg.tok_num_conv);
+    for (int k = 0; k < c->cfg.tok_num_conv; ++k) {
+      const std::string q = rp + ".tokenizer.conv" + std::to_string(k + 1);
+      const HostTensor* w = find_w(c, q + ".weight");
+      if (!w) return fail("missing weights for " + q);
+      if (find_w(c, q + ".bias")) return fail(q + ": a conv bias together with TOKENIZER.NORM is not supported");
+      RET(pack_conv(c, {w}, &R.tok_conv[k]));
+      RET(make_gn(c, q + ".norm", &R.tok_gn[k]));
+    }
+    if (c->cfg.tok_num_fc < 1) return fail("TOKENIZER.NUM_FC must be >= 1");
+    R.tok_fc.resize(c->cfg.tok_num_fc);
+    for (int k = 0; k < c->cfg.tok_num_fc; ++k) {
+      const std::string q = rp + ".tokenizer.fc" + std::to_string(k + 1);
+      if (k == 0) {
+        // nn.Flatten order is (c, p); activations here are position-major (p, c): permute the columns once
+        HostTensor* w = const_cast<HostTensor*>(find_w(c, q + ".weight"));
+        if (!w || w->shape.size() != 2 || w->shape[1] != 256 * 49) return fail("tokenizer.fc1 must take 256*7*7 inputs");
+        std::vector<float> perm(w->data.size());
+        const int O = (int)w->shape[0];
+        for (int o = 0; o < O; ++o)
+          for (int ch = 0; ch < 256; ++ch)
+            for (int pp = 0; pp < 49; ++pp) perm[(size_t)o * 12544 + pp * 256 + ch] = w->data[(size_t)o * 12544 + ch * 49 + pp];
+        w->data.swap(perm);
+      }
+      RET(make_lin(c, q, &R.tok_fc[k]));
+      if (R.tok_fc[k].O != 256) return fail("TOKENIZER.FC_DIM must be 256");
+    }
+    R.layers.resize(c->cfg.enc_layers);
+    for (int l = 0; l < c->cfg.enc_layers; ++l) {
+      const std::string q = rp + ".transformer_encoder.layers." + std::to_string(l);
+      const HostTensor *ipw = find_w(c, q + ".self_attn.in_proj_weight"), *ipb = find_w(c, q + ".self_attn.in_proj_bias");
+      const HostTensor *ow = find_w(c, q + ".self_attn.out_proj.weight"), *ob = find_w(c, q + ".self_attn.out_proj.bias");
+      if (!ipw || !ipb || !ow || !ob || ipw->data.size() != 3 * 256 * 256) return fail("missing weights for " + q);
+      // sequence length 1 => attention weights are 1: SA(x) = Wo (Wv x + bv) + bo, folded into one matrix
+      HostTensor fw, fb;
+      fw.shape = {256, 256}; fw.data.resize(256 * 256);
+      fb.shape = {256}; fb.data.resize(256);
+      const float* Wv = ipw->data.data() + 2 * 256 * 256;
+      const float* bv = ipb->data.data() + 2 * 256;
+      for (int i = 0; i < 256; ++i) {
+        for (int k = 0; k < 256; ++k) {
+          double a = 0.0;
+          for (int j = 0; j < 256; ++j) a += (double)ow->data[i * 256 + j] * (double)Wv[j * 256 + k];
+          fw.data[i * 256 + k] = (float)a;
+        }
+        double bb = ob->data[i];
+        for (int j = 0; j < 256; ++j) bb += (double)ow->data[i * 256 + j] * (double)bv[j];
+        fb.data[i] = (float)bb;
+      }
+      c->host_w[q + ".folded_attn.weight"] = fw;
+      c->host_w[q + ".folded_attn.bias"] = fb;
+      RET(make_lin(c, q + ".folded_attn", &R.layers[l].attn));
+      RET(make_lin(c, q + ".linear1", &R.layers[l].l1));
+      RET(make_lin(c, q + ".linear2", &R.layers[l].l2));
+      RET(make_ln(c, q + ".norm1", &R.layers[l].n1));
+      RET(make_ln(c, q + ".norm2", &R.layers[l].n2));
+    }
+    if (c->cfg.head_num_fc < 1 || c->cfg.head_num_fc > 2) return fail("HEAD.NUM_FC must be 1 or 2");
+    R.wh.resize(c->cfg.head_num_fc); R.bh.resize(c->cfg.head_num_fc);
+    for (int k = 0; k < c->cfg.head_num_fc; ++k) {
+      RET(make_lin(c, rp + ".weight_head.fc" + std::to_string(k + 1), &R.wh[k]));
+      RET(make_lin(c, rp + ".bias_head.fc" + std::to_string(k + 1), &R.bh[k]));
+    }
+    if (R.wh.back().O != 256 || R.bh.back().O != 1) return fail("HEAD.OUTPUT_DIM must be 256");
+    c->has_roienc = true;
   }
   c->host_w.clear();
   c->finalized = true;
@@ -1051,7 +1286,8 @@ int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
   Plan* P = c->cur;
   if (!P) return fail("no current batch");
   if (!boxes || !code_out) return fail("NULL argument");
-  RET(build_support(c, P));
+  if (c->cfg.cg_type == 1) RET(build_support_roienc(c, P));
+  else RET(build_support(c, P));
   P->cur_boxes = boxes;
   P->cur_code_out = code_out;
   return run_ops(c, P->support_ops, "codegen");

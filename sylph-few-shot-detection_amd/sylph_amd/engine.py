@@ -65,6 +65,22 @@ def config_from_cfg(cfg) -> SylphConfig:
     sc.prior_prob = float(f.PRIOR_PROB)
     cg = m.META_LEARN.CODE_GENERATOR
     sc.cond_use_bias = int(bool(cg.USE_BIAS))
+    if str(cg.NAME) == "ROIEncoder":
+        # sylph/modeling/code_generator/roi_encoder.py:206-281 (dims of the LVIS ROI-Encoder yaml)
+        sc.cg_type = 1
+        tk, te, hd = cg.TOKENIZER, cg.TRANSFORMER_ENCODER, cg.HEAD
+        if int(tk.CONV_DIM) != 256 or int(tk.FC_DIM) != 256 or int(hd.OUTPUT_DIM) != 256:
+            raise NotImplementedError("ROIEncoder: TOKENIZER.CONV_DIM / FC_DIM and HEAD.OUTPUT_DIM must be 256")
+        if int(tk.NUM_CONV) > 0 and str(tk.NORM) != "GN":
+            raise NotImplementedError("ROIEncoder: TOKENIZER.NORM must be 'GN'")
+        if int(cg.ROI_BOX.POOLER_RESOLUTION) != 7:
+            raise NotImplementedError("ROI_BOX.POOLER_RESOLUTION must be 7")
+        sc.tok_num_conv, sc.tok_num_fc = int(tk.NUM_CONV), int(tk.NUM_FC)
+        sc.enc_layers, sc.head_num_fc, sc.head_fc_dim = int(te.LAYERS), int(hd.NUM_FC), int(hd.FC_DIM)
+        sc.cond_use_bias = 1  # CondConvBlock always passes the bias (head_utils.py:140-162)
+        return sc
+    if str(cg.NAME) != "CodeGenerator":
+        raise NotImplementedError(f"{cg.NAME} is not implemented")
     tl = list(cg.TOWER_LAYERS)
     for layer in tl:
         if list(layer) != ["GN", "ReLU"]:
@@ -106,6 +122,8 @@ class Engine:
             self.sc.cand_cap = cand_cap
         check(self.L.sylph_set_config(self._ctx, ctypes.byref(self.sc)), "set_config")
         self.nlevels = self.sc.nlevels
+        self.is_roi_encoder = int(self.sc.cg_type) == 1
+        self.cond_scale = 1.0  # CondConvBlock Scale (ROIEncoder head), read from the checkpoint
         self._batch = None  # (B, H, W, [(h,w)...])
         self._ncls = 0
         self._keep = []  # tensors that must outlive queued kernels
@@ -130,6 +148,8 @@ class Engine:
         for k, v in sd.items():
             if not torch.is_tensor(v) or not v.is_floating_point():
                 continue
+            if k.endswith("fcos_head.cond_cls_logits.scales.0.scale"):
+                self.cond_scale = float(v.reshape(-1)[0])
             t = v.detach().to("cpu", torch.float32).contiguous()
             shape = (c_int64 * max(t.dim(), 1))(*(list(t.shape) if t.dim() else [1]))
             check(self.L.sylph_load_weight(self._ctx, k.encode(), c_void_p(t.data_ptr()), shape, max(t.dim(), 1)),
@@ -193,6 +213,10 @@ class Engine:
         assert cls_conv.size(1) == 256 and cls_conv.size(2) == 1 and cls_conv.size(3) == 1
         w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256).contiguous()
         b = cls_bias.to(self.device, torch.float32).reshape(-1).contiguous() if cls_bias is not None else None
+        if self.is_roi_encoder and self.cond_scale != 1.0:
+            # CondConvBlock with one 256-channel chunk: scale * conv(feature, w, bias) (head_utils.py:146-150)
+            w = w * self.cond_scale
+            b = b * self.cond_scale if b is not None else None
         if b is not None:
             assert b.numel() == w.size(0)
         self._codes = (w, b)

@@ -77,7 +77,8 @@ def CodeGenerator(cfg, feature_channels=256, feature_levels=5, strides=None):
 
 @CODE_GENERATOR_REGISTRY.register()
 def ROIEncoder(cfg, feature_channels=256, feature_levels=5, strides=None):
-    raise NotImplementedError("the ROIEncoder code generator (SURVEY.md 8a a22) is not built yet")
+    assert feature_channels == 256, "Each level must have the same channel!"
+    return {"name": "ROIEncoder", "eval_shot": int(cfg.MODEL.META_LEARN.EVAL_SHOT)}
 
 
 def build_code_generator(cfg, feature_channels, feature_levels, strides):
@@ -168,15 +169,26 @@ class MetaOneStageDetector(nn.Module):
                 gt = gt[np.random.choice(range(len(gt)), 1)]
             boxes.append(gt.reshape(1, 4))
         eng = self.engine
+        if eng.is_roi_encoder:
+            # roi_encoder.py:156-166: num_shots = EVAL_SHOT in eval, batch = total / num_shots (one class here)
+            num_shots = self.code_generator["eval_shot"]
+            assert len(records) % num_shots == 0, f"{len(records)} % {num_shots}"
+            assert len(records) // num_shots == 1, "one class per call at inference"
         eng.preprocess([rec["image"] for rec in records])
         eng.backbone()
         code = eng.codegen(torch.cat(boxes, dim=0))
+        if eng.is_roi_encoder:
+            return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1)}
         return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
 
     def normalize_class_code(self, codes: List[Dict]):
         """code_generator.py:877-897 via meta_one_stage_detector.py:256-259 (mutates the list)."""
         assert self.episodic_learning
         assert not self.training
+        if self.engine.is_roi_encoder:
+            # the reference fails the same way: ROIEncoder.forward() takes no cls_norm/class_codes
+            # (meta_one_stage_detector.py:259 -> roi_encoder.py:146)
+            raise TypeError("ROIEncoder.forward() got an unexpected keyword argument 'cls_norm'")
         assert codes is not None
         if len(codes) == 0:
             return codes

@@ -125,7 +125,8 @@ class MetaFCOSRunner:
             by_cid = {int(c["support_set_target"]): c for c in base}
             codes = [dict(c, class_code=by_cid[int(c["support_set_target"])]["class_code"])
                      if int(c["support_set_target"]) in by_cid else c for c in codes]
-        codes = inference_normalization(model, codes)
+        if str(cfg.MODEL.META_LEARN.CODE_GENERATOR.NAME) != "ROIEncoder":
+            codes = inference_normalization(model, codes)  # ROIEncoder codes need none (and the reference call raises)
         if num_classes is not None:
             assert len(codes) == num_classes, \
                 f"Got {len(codes)} class codes for prediction, but expect to be {num_classes}."

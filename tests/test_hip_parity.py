@@ -316,3 +316,39 @@ def test_full_size_properties_bf16(full_sd):
         iou = inter / (area[:, None] + area[None, :] - inter)
         same = (cl[:, None] == cl[None, :]) & ~torch.eye(len(cl), dtype=torch.bool)
         assert (iou[same] <= 0.75).all()
+
+
+# --------------------------------------------------------------------------------- ROIEncoder (C5)
+def _roienc_cfg():
+    cfg = _cfg(True)
+    cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+    cg.NAME = "ROIEncoder"
+    cg.TOKENIZER.NUM_CONV, cg.TOKENIZER.CONV_DIM, cg.TOKENIZER.NORM = 2, 256, "GN"
+    cg.TOKENIZER.NUM_FC, cg.TOKENIZER.FC_DIM = 2, 256
+    cg.TRANSFORMER_ENCODER.LAYERS, cg.TRANSFORMER_ENCODER.HEADS = 2, 8
+    cg.HEAD.NUM_FC, cg.HEAD.FC_DIM, cg.HEAD.OUTPUT_DIM = 2, 512, 256
+    return cfg
+
+
+@pytest.mark.parametrize("S", [2, 5])
+def test_roi_encoder_matches_reference_golden(golden_dir, S):
+    from oracle import weights as W
+    g = np.load(os.path.join(golden_dir, "g7_roi_encoder.npz"))
+    eng = _engine("f32", _roienc_cfg())
+    eng.load_state_dict(W.roi_encoder_state_dict(seed=4))
+    assert eng.is_roi_encoder and abs(eng.cond_scale - 0.8) < 1e-6
+    eng.import_pyramid(_feats(g, f"s{S}_feat"), (192, 256))
+    code = eng.codegen(torch.from_numpy(g[f"s{S}_boxes"])).cpu().numpy()
+    np.testing.assert_allclose(code[:256], g[f"s{S}_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(code[256], g[f"s{S}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
+
+
+def test_roi_encoder_bf16_close(golden_dir):
+    from oracle import weights as W
+    g = np.load(os.path.join(golden_dir, "g7_roi_encoder.npz"))
+    eng = _engine("bf16", _roienc_cfg())
+    eng.load_state_dict(W.roi_encoder_state_dict(seed=4))
+    eng.import_pyramid(_feats(g, "s5_feat"), (192, 256))
+    code = eng.codegen(torch.from_numpy(g["s5_boxes"])).cpu()
+    ref = torch.from_numpy(g["s5_cls_conv"].reshape(-1))
+    assert F.cosine_similarity(code[:256], ref, dim=0).item() > 0.995
