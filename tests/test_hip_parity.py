@@ -352,3 +352,73 @@ def test_roi_encoder_bf16_close(golden_dir):
     code = eng.codegen(torch.from_numpy(g["s5_boxes"])).cpu()
     ref = torch.from_numpy(g["s5_cls_conv"].reshape(-1))
     assert F.cosine_similarity(code[:256], ref, dim=0).item() > 0.995
+
+
+# --------------------------------------------------------------------------------- C3 / C4 shaped cases
+def test_r101_backbone_matches_oracle_f32():
+    """BASELINE config C4 backbone (MODEL.RESNETS.DEPTH 101) at small size."""
+    from oracle import backbone as OB, weights as W
+    sd = W.backbone_state_dict(0, depth=101)
+    imgs = W.synthetic_images(1, 96, 128, seed=8)
+    eng = _engine("f32", _cfg(**{"MODEL.RESNETS.DEPTH": 101}))
+    eng.load_state_dict(sd)
+    eng.preprocess(imgs)
+    eng.backbone()
+    got = eng.export_pyramid()
+    x, _ = OB.preprocess(imgs)
+    ref = OB.backbone_fpn(x, sd, 101)
+    for l in range(5):
+        err = (got[l].cpu() - ref[l]).abs().max().item()
+        assert err <= 1e-3 * max(1.0, ref[l].abs().max().item()), f"level {l}: {err}"
+
+
+@pytest.mark.parametrize("N,thr,post", [(337, 0.02, 300), (866, 0.03, 300), (20, 0.011, 100)])
+def test_many_class_decode_topk_matches_oracle(g1, N, thr, post):
+    """Many-way decode (LVIS-sized N): > PRE_NMS_TOPK candidates on a level -> exact radix top-k, NMS, keep
+    POST_NMS_TOPK(+ties).  Decode is checked on the SAME head outputs (exported), so every difference is decode."""
+    from oracle import decode as OD, weights as W
+    cfg = _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": thr, "MODEL.FCOS.POST_NMS_TOPK_TEST": post})
+    eng = _engine("f32", cfg)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    codes = W.synthetic_codes(N, seed=77, scale=2.0)
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    lo, rg, ct, io = [[t.cpu() for t in ts] for ts in eng.export_head()]
+    want = OD.predict_proposals(lo, rg, ct, io, pre_nms_thresh=thr, post_nms_topk=post)
+    ncand_l0 = int((lo[0][0].sigmoid() > thr).sum())
+    assert ncand_l0 > 1000, f"case does not exercise top-k ({ncand_l0})"
+    got = eng.decode()
+    for i, (w, g) in enumerate(zip(want, got)):
+        w = OD.detector_postprocess(w, sizes[i], sizes[i][0], sizes[i][1])
+        assert g["scores"].numel() == w["scores"].numel()
+        np.testing.assert_array_equal(g["pred_classes"].cpu().numpy(), w["pred_classes"].numpy())
+        np.testing.assert_array_equal(g["locations"].cpu().numpy(), w["locations"].numpy())
+        np.testing.assert_allclose(g["scores"].cpu().numpy(), w["scores"].numpy(), atol=1e-5)
+        np.testing.assert_allclose(g["pred_boxes"].cpu().numpy(), w["pred_boxes"].numpy(), atol=1e-3)
+
+
+def test_candidate_overflow_fails_loudly(g1):
+    from oracle import weights as W
+    eng = _engine("f32", _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": 0.011}), cand_cap=64)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    eng.import_pyramid(_feats(g1), (128, 160))
+    codes = W.synthetic_codes(20, seed=50, scale=2.5)
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    with pytest.raises(RuntimeError, match="candidate capacity"):
+        eng.decode()
+
+
+def test_c3_shape_runs_bf16(full_sd):
+    """BASELINE config C3 shape: 20-way, batch 16 queries (smaller images to keep the test short)."""
+    from oracle import weights as W
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(full_sd)
+    q = W.synthetic_images(16, 256, 320, seed=12)
+    codes = W.synthetic_codes(20, seed=13, scale=3.0)
+    eng.preprocess(q)
+    eng.backbone()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    dets = eng.decode()
+    assert len(dets) == 16 and all(d["scores"].numel() > 0 for d in dets)
+    assert all(int(d["pred_classes"].max()) < 20 for d in dets)
