@@ -66,15 +66,16 @@ template <> struct Mma<float> {
 };
 
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AR = BM / 32, BR = BN / 32;  // wave-level loads per slice (8 rows each)
+  constexpr int NT = WGM * WGN * 64;         // threads per block (4 or 8 waves)
+  constexpr int RS = NT / 8;                 // tile rows staged by one load instruction of the whole block
+  constexpr int AR = BM / RS, BR = BN / RS;  // wave-level loads per slice (8 rows each)
   constexpr int STAGE = (BM + BN) * 128;
-  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad tile");
-  static_assert(WTM * BN * 4 <= NBUF * STAGE, "epilogue tile does not fit the staging LDS");
+  static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   uint32_t amask[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int pos = tile.y + r0 + 32 * i;
+    const int pos = tile.y + r0 + RS * i;
     const bool rv = pos < seg_rows;
     const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
     uint32_t m = 0;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
   size_t bbase[BR];
 #pragma unroll
-  for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + 32 * j) * Ktot + cl * EPC;
+  for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + RS * j) * Ktot + cl * EPC;
 
   int tap = 0, cc = 0, kh = 0, kw = 0;  // state of the NEXT slice to fetch
   auto issue = [&](int buf) {
@@ -150,11 +151,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const T* src = ((amask[i] >> tap) & 1u) ? in + (abase[i] + aoff) : zero + cl * EPC;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dA + i * 32 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dA + i * RS * 128), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + (bbase[j] + boff)), (lds_ptr_t)(dB + j * 32 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + (bbase[j] + boff)), (lds_ptr_t)(dB + j * RS * 128), 16, 0, 0);
     if (++cc == cpt) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
   };
 
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   // one row: 16-byte residual loads, 16-byte (bf16) / 32-byte (fp32) stores, 256 B per 16 lanes.
   float* const sC = reinterpret_cast<float*>(smem);
   constexpr int TPR = BN / 8;     // lanes per output row
-  constexpr int RPP = 256 / TPR;  // rows per sweep
+  constexpr int RPP = NT / TPR;   // rows per sweep
   OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out);
   const T* __restrict__ res = reinterpret_cast<const T*>(a.res);
   const int c8 = tid % TPR, rr = tid / TPR;
@@ -327,9 +328,11 @@ template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  const size_t lds = (size_t)NBUF * (BM + BN) * 128;
+  const size_t stage = (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * BN * 4;
+  const size_t lds = stage > epi ? stage : epi;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), lds, s, a);
   return (int)hipGetLastError();
 }
 
@@ -338,6 +341,8 @@ void conv_set_nbuf(int n) { g_nbuf = n == 2 ? 2 : 1; }
 
 template <typename T, typename OutT, int NBUF>
 static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
+  if (BM == 256 && BN == 128) return launch_cfg<T, OutT, 256, 128, 4, 2, NBUF>(a, s);
+  if (BM == 128 && BN == 256) return launch_cfg<T, OutT, 128, 256, 2, 4, NBUF>(a, s);
   if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2, NBUF>(a, s);
   if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2, NBUF>(a, s);
   if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1, NBUF>(a, s);
@@ -359,13 +364,19 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
   if (ntaps == 1 && bn == 128 && cout % 64 == 0) bn = 64;
   if (const char* f = getenv("SYLPH_CONV_FORCE_BN")) {  // tuning knob
     const int v = atoi(f);
-    if ((v == 64 || v == 128) && cout % v == 0) bn = v;
+    if ((v == 64 || v == 128 || v == 256) && cout % v == 0) bn = v;
   }
   int bm = 128;
   if (bn != 32) {
     const long blocks128 = (long)((rows_total + 127) / 128) * ((cout + bn - 1) / bn);
     if (blocks128 < 1024) bm = 64;
   }
+  if (const char* f = getenv("SYLPH_CONV_FORCE_BM")) {  // tuning knob
+    const int v = atoi(f);
+    if ((v == 64 || v == 128 || v == 256) && bn != 32) bm = v;
+  }
+  if (bn == 256) bm = 128;
+  if (bm == 256 && bn != 128) bm = 128;
   *BM = bm;
   *BN = bn;
 }
