@@ -22,7 +22,7 @@ struct SegDesc {
   int out_row0, out_H, out_W;
   int res_row0, res_H, res_W;  // residual source geometry (res_mode 2: half resolution)
   float mul;                   // per-segment multiplier (FCOS Scale_l), applied to channels < mul_nch
-  int pad0, pad1;
+  int in2_row0, in2_W;         // second input (dual-source pointwise conv): first row, row width
 };
 
 struct ConvArgs {
@@ -32,12 +32,14 @@ struct ConvArgs {
   const void* res;    // optional residual (compute dtype), row stride res_ld
   const float* scale; // per-output-channel epilogue scale (nullptr -> 1)
   const float* shift; // per-output-channel epilogue shift (nullptr -> 0)
+  const void* in2;    // optional second input of a dual-source pointwise conv (see conv_igemm.hip)
   const void* zeros;  // >= 128 B of zeros: source of out-of-image taps (global_load_lds cannot predicate)
   const SegDesc* segs;
   const int2* tiles;  // tiles[t] = {segment, first row of the tile inside the segment}
   int n_mtiles, n_ntiles;
   int Cin, Cout, KH, KW, stride, pad;
   int in_ld, out_ld, res_ld;  // row strides in elements
+  int Cin2, in2_ld, stride2;  // second input: channels, row stride, spatial stride
   int relu_nch;               // ReLU on output channels < relu_nch
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res

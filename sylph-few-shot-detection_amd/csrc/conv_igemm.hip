@@ -103,10 +103,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
   const T* __restrict__ zero = reinterpret_cast<const T*>(a.zeros);
   const int Cin = a.Cin, KW = a.KW, ntaps = a.KH * a.KW;
   const int cpt = Cin / BK;            // K-slices per tap
-  const int nk = ntaps * cpt;
-  const int Ktot = ntaps * Cin;
+  // Dual-source pointwise mode (a.in2): K = [Cin channels of `in` | Cin2 channels of `in2`], the
+  // second source sampled with its own spatial stride (bottleneck conv3 + projection shortcut in
+  // one GEMM; FrozenBN scales are pre-folded into the weights, shifts summed).
+  const T* __restrict__ in2 = reinterpret_cast<const T*>(a.in2);
+  const int cpt2 = in2 ? a.Cin2 / BK : 0;
+  const int nk = ntaps * cpt + cpt2;
+  const int Ktot = ntaps * Cin + (in2 ? a.Cin2 : 0);
 
-  int abase[AR];
+  int abase[AR], abase2[AR];
   uint32_t amask[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
@@ -137,6 +142,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
       }
     }
     amask[i] = m;
+    if (in2) {
+      abase2[i] = (sd.in2_row0 + (oy * a.stride2) * sd.in2_W + ox * a.stride2) * a.in2_ld + cl * EPC;
+      if (rv) amask[i] |= 1u << 31;
+    }
   }
   size_t bbase[BR];
 #pragma unroll
@@ -146,17 +155,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
   auto issue = [&](int buf) {
     char* dA = smem + buf * STAGE + wave * 8 * 128;  // wave-uniform: lane l lands at +16*l
     char* dB = dA + BM * 128;
-    const int aoff = (kh * a.tap_dy * sd.in_W + kw) * a.in_ld + cc * BK;
+    const bool second = tap >= ntaps;  // only in dual-source mode
+    const int aoff = second ? cc * BK : (kh * a.tap_dy * sd.in_W + kw) * a.in_ld + cc * BK;
     const int boff = tap * Cin + cc * BK;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const T* src = ((amask[i] >> tap) & 1u) ? in + (abase[i] + aoff) : zero + cl * EPC;
+      const T* src;
+      if (second) src = (amask[i] >> 31) ? in2 + (abase2[i] + aoff) : zero + cl * EPC;
+      else src = ((amask[i] >> tap) & 1u) ? in + (abase[i] + aoff) : zero + cl * EPC;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dA + i * RS * 128), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + (bbase[j] + boff)), (lds_ptr_t)(dB + j * RS * 128), 16, 0, 0);
-    if (++cc == cpt) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
+    if (++cc == cpt && !second) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
   };
 
   f32x16 acc[TM][TN];
@@ -382,9 +394,10 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
 }
 
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s) {
-  if (a.KH * a.KW > 32) return -3;
+  if (a.KH * a.KW > 31) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
   if (a.Cin % bk != 0) return -4;
+  if (a.in2 && (a.Cin2 % bk != 0 || a.KH * a.KW != 1)) return -6;
   if (!a.zeros) return -5;
   if (dt == DT_BF16) {
     return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);

@@ -80,7 +80,7 @@ struct sylph_ctx {
   std::map<std::string, HostTensor> host_w;
   // packed model
   ConvLayer stem;  // 7x7 s2 stem packed for the implicit-GEMM stem loader
-  struct Block { ConvLayer c1, c2, c3, sc; bool has_sc = false; };
+  struct Block { ConvLayer c1, c2, c3, sc, c3sc; bool has_sc = false, fused_sc = false; };
   std::vector<std::vector<Block>> stages;  // res2..res5
   ConvLayer fpn_lat[3], fpn_out[3], p6, p7;  // index 0..2 = stage 3..5
   std::vector<ConvLayer> cls_tower, box_tower;
@@ -358,6 +358,8 @@ struct ConvOpts {
   int cout_override = -1;  // logical Cout (class-conditional conv)
   int stem = 0;            // ResNet stem loader
   int want_gn = 0;         // leave per-tile GroupNorm partials in the epilogue
+  const void* in2 = nullptr;  // dual-source pointwise conv: second input, its row stride / channels / stride
+  int in2_ld = 0, Cin2 = 0, stride2 = 1;
   double flops = -1.0;     // algorithmic FLOPs of the launch when they differ from 2*M*N*K (stem padding)
 };
 
@@ -380,6 +382,10 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode;
   a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
+  if (o.in2) {
+    a.in2 = o.in2; a.in2_ld = o.in2_ld; a.Cin2 = o.Cin2; a.stride2 = o.stride2;
+    a.Cin = L.Cin - o.Cin2;  // the packed weights hold both K ranges back to back
+  }
   if (o.want_gn) {
     if (L.Cout != 256) return fail("fused GroupNorm statistics need Cout == 256");
     RET(c->dalloc((void**)&a.gn_partial, (size_t)g.n_mtiles * 32 * 3 * sizeof(float)));
@@ -501,15 +507,24 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
       RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
       ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
       RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
-      const void* resid = X;
-      if (blk.has_sc) {
-        ConvOpts os; os.stride = stride;
-        RET(add_conv(c, ops, blk.sc, X, Cin, sc, cout, image_segs(B, Hin, Win, Ho, Wo), os));
-        resid = sc;
-      }
       Y = (Y == Ya) ? Yb : Ya;
-      ConvOpts o3; o3.relu_nch = 1 << 30; o3.res = resid; o3.res_ld = cout; o3.res_mode = 1;
-      RET(add_conv(c, ops, blk.c3, t2, mid, Y, cout, image_segs(B, Ho, Wo, Ho, Wo), o3));
+      if (blk.fused_sc) {
+        // conv3 + projection shortcut as ONE pointwise GEMM over K = [t2 | X(strided)]: the shortcut
+        // tensor is never written to / re-read from HBM
+        std::vector<SegDesc> sg = image_segs(B, Ho, Wo, Ho, Wo);
+        for (int b = 0; b < B; ++b) { sg[b].in2_row0 = b * Hin * Win; sg[b].in2_W = Win; }
+        ConvOpts o3; o3.relu_nch = 1 << 30; o3.in2 = X; o3.in2_ld = Cin; o3.Cin2 = Cin; o3.stride2 = stride;
+        RET(add_conv(c, ops, blk.c3sc, t2, mid, Y, cout, sg, o3));
+      } else {
+        const void* resid = X;
+        if (blk.has_sc) {
+          ConvOpts os; os.stride = stride;
+          RET(add_conv(c, ops, blk.sc, X, Cin, sc, cout, image_segs(B, Hin, Win, Ho, Wo), os));
+          resid = sc;
+        }
+        ConvOpts o3; o3.relu_nch = 1 << 30; o3.res = resid; o3.res_ld = cout; o3.res_mode = 1;
+        RET(add_conv(c, ops, blk.c3, t2, mid, Y, cout, image_segs(B, Ho, Wo, Ho, Wo), o3));
+      }
       X = Y; Hin = Ho; Win = Wo; Cin = cout;
     }
     stage_out[si] = X; stage_h[si] = Hin; stage_w[si] = Win;
@@ -988,6 +1003,35 @@ int sylph_finalize_weights(sylph_ctx* c) {
         RET(make_conv_bn(c, q + ".conv3", &blk.c3));
         blk.has_sc = bi == 0;
         if (blk.has_sc) RET(make_conv_bn(c, q + ".shortcut", &blk.sc));
+        const char* fz = getenv("SYLPH_FUSE_SHORTCUT");
+        if (blk.has_sc && !(fz && atoi(fz) == 0)) {
+          // fold the two FrozenBN scales into the weights, sum the shifts (fp32 before the dtype cast)
+          const HostTensor *w3 = find_w(c, q + ".conv3.weight"), *ws = find_w(c, q + ".shortcut.weight");
+          const int co = (int)w3->shape[0], k3 = (int)w3->shape[1], ks = (int)ws->shape[1];
+          std::vector<float> s3(co), h3(co), ss(co), hs(co);
+          for (int i = 0; i < co; ++i) {
+            const float a3 = find_w(c, q + ".conv3.norm.weight")->data[i] *
+                             (1.0f / sqrtf(find_w(c, q + ".conv3.norm.running_var")->data[i] + 1e-5f));
+            s3[i] = a3;
+            h3[i] = find_w(c, q + ".conv3.norm.bias")->data[i] - find_w(c, q + ".conv3.norm.running_mean")->data[i] * a3;
+            const float as = find_w(c, q + ".shortcut.norm.weight")->data[i] *
+                             (1.0f / sqrtf(find_w(c, q + ".shortcut.norm.running_var")->data[i] + 1e-5f));
+            ss[i] = as;
+            hs[i] = find_w(c, q + ".shortcut.norm.bias")->data[i] - find_w(c, q + ".shortcut.norm.running_mean")->data[i] * as;
+          }
+          HostTensor hc;
+          hc.shape = {co, k3 + ks, 1, 1};
+          hc.data.resize((size_t)co * (k3 + ks));
+          std::vector<float> shift(co);
+          for (int i = 0; i < co; ++i) {
+            for (int k = 0; k < k3; ++k) hc.data[(size_t)i * (k3 + ks) + k] = w3->data[(size_t)i * k3 + k] * s3[i];
+            for (int k = 0; k < ks; ++k) hc.data[(size_t)i * (k3 + ks) + k3 + k] = ws->data[(size_t)i * ks + k] * ss[i];
+            shift[i] = h3[i] + hs[i];
+          }
+          RET(pack_conv(c, {&hc}, &blk.c3sc));
+          RET(upload_vec(c, &blk.c3sc.shift, shift, blk.c3sc.Cout_pad));
+          blk.fused_sc = true;
+        }
       }
     }
     for (int k = 0; k < 3; ++k) {
