@@ -40,6 +40,7 @@ struct ConvArgs {
   int Cin, Cout, KH, KW, stride, pad;
   int in_ld, out_ld, res_ld;  // row strides in elements
   int Cin2, in2_ld, stride2;  // second input: channels, row stride, spatial stride
+  int group_cout, group_in_off;  // grouped conv: output channels per group, input-channel offset per group (0 = off)
   int relu_nch;               // ReLU on output channels < relu_nch
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res

@@ -147,6 +147,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
       if (rv) amask[i] |= 1u << 31;
     }
   }
+  if (a.group_cout > 0) {  // grouped conv: this N tile's group reads its own input-channel window
+    const int goff = ((nt * BN) / a.group_cout) * a.group_in_off;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) abase[i] += goff;
+  }
   size_t bbase[BR];
 #pragma unroll
   for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + RS * j) * Ktot + cl * EPC;

@@ -200,8 +200,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
 
 // Fused variant: the conv epilogue already left (n, mean, M2) per (M-tile, group); every block folds
 // the partials of its segment in tile order (deterministic, fp64) and applies the affine (+ReLU).
+// ngroups = C/8 (32 for one tower, 64 for the paired cls|bbox towers held side by side).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ x, const GnSeg* segs, int ld,
+__global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ x, const GnSeg* segs, int ld, int ngroups,
                                                                 int rows_per_chunk,
                                                                 const float* __restrict__ partial, float eps,
                                                                 const float* __restrict__ gamma,
@@ -211,12 +212,12 @@ __global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ 
   const int r_begin = chunk * rows_per_chunk;
   if (r_begin >= sg.nrows) return;
   const int r_end = min(sg.nrows, r_begin + rows_per_chunk);
-  const int g = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  __shared__ float2 st_sh[32];
-  if (threadIdx.x < 32) {
+  const int g = threadIdx.x % ngroups, rl = threadIdx.x / ngroups, rstep = 256 / ngroups;
+  __shared__ float2 st_sh[64];
+  if ((int)threadIdx.x < ngroups) {
     double N = 0.0, M = 0.0, Q = 0.0;
     for (int t = 0; t < sg.ntiles; ++t) {
-      const float* p = partial + ((size_t)(sg.tile0 + t) * 32 + g) * 3;
+      const float* p = partial + ((size_t)(sg.tile0 + t) * ngroups + g) * 3;
       const double nb = p[0], mb = p[1], qb = p[2];
       if (nb > 0.0) {
         const double nn = N + nb, delta = mb - M;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ 
     a[j] = st.y * gamma[g * 8 + j];
     b[j] = beta[g * 8 + j] - st.x * a[j];
   }
-  for (int r = r_begin + rl; r < r_end; r += 8) {
+  for (int r = r_begin + rl; r < r_end; r += rstep) {
     T* p = x + (size_t)(sg.row0 + r) * ld + g * 8;
     float v[8];
     load8<T>(p, v);
@@ -250,17 +251,18 @@ __global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ 
   }
 }
 
-int launch_gn_apply_partials(DType dt, void* x, int ld, const GnSeg* segs_dev, int nseg, int max_rows,
+int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg* segs_dev, int nseg, int max_rows,
                              const float* partial, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s) {
+  if (ngroups != 32 && ngroups != 64) return -1;
   const int rpc = GN_ROWS_PER_CHUNK;
   dim3 grid((max_rows + rpc - 1) / rpc, nseg), block(256);
   if (dt == DT_BF16)
-    hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, rpc, partial, eps,
-                       gamma, beta, relu);
+    hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, ngroups, rpc, partial,
+                       eps, gamma, beta, relu);
   else
-    hipLaunchKernelGGL(gn_apply_partials_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, rpc, partial, eps,
-                       gamma, beta, relu);
+    hipLaunchKernelGGL(gn_apply_partials_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, ngroups, rpc, partial,
+                       eps, gamma, beta, relu);
   return (int)hipGetLastError();
 }
 

@@ -85,6 +85,9 @@ struct sylph_ctx {
   ConvLayer fpn_lat[3], fpn_out[3], p6, p7;  // index 0..2 = stage 3..5
   std::vector<ConvLayer> cls_tower, box_tower;
   std::vector<GNLayer> cls_gn, box_gn;
+  std::vector<ConvLayer> pair_tower;  // cls|bbox towers stacked on Cout (layer 0 shares the input, then grouped)
+  std::vector<GNLayer> pair_gn;
+  bool paired = false;
   ConvLayer pred;  // bbox_pred(4) + ctrness(1) + iou_overlap(1)
   std::vector<float> level_scales;
   std::vector<ConvLayer> cg_tower;
@@ -138,6 +141,7 @@ struct Plan {
   // head
   void *tA = nullptr, *tB = nullptr, *tC = nullptr, *tD = nullptr;
   void* cls_feat = nullptr;  // output of the cls tower (input of the class-conditional conv)
+  int cls_ld = 256;
   float* pred = nullptr;    // [rows][8]
   float* logits = nullptr;  // [rows][logits_ld]
   int logits_ld = 0, logits_cap_ld = 0, ncls = 0;
@@ -356,6 +360,7 @@ struct ConvOpts {
   int res_ld = 0, res_mode = 0;
   bool out_f32 = false;
   int cout_override = -1;  // logical Cout (class-conditional conv)
+  int group_cout = 0, group_in_off = 0;  // grouped conv (paired FCOS towers)
   int stem = 0;            // ResNet stem loader
   int want_gn = 0;         // leave per-tile GroupNorm partials in the epilogue
   const void* in2 = nullptr;  // dual-source pointwise conv: second input, its row stride / channels / stride
@@ -382,13 +387,14 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode;
   a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
+  a.group_cout = o.group_cout; a.group_in_off = o.group_in_off;
   if (o.in2) {
     a.in2 = o.in2; a.in2_ld = o.in2_ld; a.Cin2 = o.Cin2; a.stride2 = o.stride2;
     a.Cin = L.Cin - o.Cin2;  // the packed weights hold both K ranges back to back
   }
   if (o.want_gn) {
-    if (L.Cout != 256) return fail("fused GroupNorm statistics need Cout == 256");
-    RET(c->dalloc((void**)&a.gn_partial, (size_t)g.n_mtiles * 32 * 3 * sizeof(float)));
+    if (L.Cout != 256 && L.Cout != 512) return fail("fused GroupNorm statistics need Cout == 256 or 512");
+    RET(c->dalloc((void**)&a.gn_partial, (size_t)g.n_mtiles * (L.Cout / 8) * 3 * sizeof(float)));
   }
   if (geom_out) { *geom_out = g; geom_out->gn_partial = a.gn_partial; }
   const DType dt = c->dt;
@@ -403,7 +409,8 @@ static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L,
                        const std::vector<SegDesc>& segs, ConvOpts o, const GNLayer& G, int relu) {
   o.want_gn = 1;
   Geom g;
-  RET(add_conv(c, ops, L, in, in_ld, out, 256, segs, o, &g));
+  const int ld = L.Cout, ngroups = L.Cout / 8;
+  RET(add_conv(c, ops, L, in, in_ld, out, ld, segs, o, &g));
   const float* partial = g.gn_partial;
   std::vector<GnSeg> gs;
   int max_rows = 0;
@@ -418,7 +425,7 @@ static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L,
   const int nseg = (int)gs.size();
   const float *ga = G.gamma, *be = G.beta;
   ops.push_back([=](hipStream_t s) {
-    return launch_gn_apply_partials(dt, out, 256, gsd, nseg, max_rows, partial, ga, be, 1e-5f, relu, s);
+    return launch_gn_apply_partials(dt, out, ld, ngroups, gsd, nseg, max_rows, partial, ga, be, 1e-5f, relu, s);
   });
   return 0;
 }
@@ -619,10 +626,10 @@ static int build_head(sylph_ctx* c, Plan* P) {
   const size_t e = c->esz();
   const size_t rows = (size_t)P->B * P->Ltot;
   const int L = c->cfg.nlevels, nseg = P->B * L;
-  RET(c->dalloc(&P->tA, rows * 256 * e));
-  RET(c->dalloc(&P->tB, rows * 256 * e));
-  RET(c->dalloc(&P->tC, rows * 256 * e));
-  RET(c->dalloc(&P->tD, rows * 256 * e));
+  RET(c->dalloc(&P->tA, rows * 512 * e));  // paired towers: [rows][512]; unpaired: tA/tB = halves
+  RET(c->dalloc(&P->tC, rows * 512 * e));
+  P->tB = (char*)P->tA + rows * 256 * e;
+  P->tD = (char*)P->tC + rows * 256 * e;
   RET(c->dalloc((void**)&P->pred, rows * 8 * sizeof(float)));
   std::vector<RowSeg> rs;
   for (int b = 0; b < P->B; ++b)
@@ -648,10 +655,29 @@ static int build_head(sylph_ctx* c, Plan* P) {
     return 0;
   };
   void *cls_feat = nullptr, *box_feat = nullptr;
-  RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat));
-  RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat));
+  int feat_ld = 256;
+  if (c->paired) {
+    // tA|tB and tC|tD are used as two [rows][512] ping-pong buffers
+    const void* in = P->F;
+    int in_ld = 256;
+    void* out = P->tA;
+    for (size_t i = 0; i < c->pair_tower.size(); ++i) {
+      ConvOpts o; o.pad = 1;
+      if (i > 0) { o.group_cout = 256; o.group_in_off = 256; }
+      RET(add_conv_gn(c, ops, c->pair_tower[i], in, in_ld, out, segs, o, c->pair_gn[i], 1));
+      in = out; in_ld = 512;
+      out = (out == P->tA) ? P->tC : P->tA;
+    }
+    cls_feat = const_cast<void*>(in);
+    box_feat = (char*)cls_feat + 256 * e;
+    feat_ld = 512;
+  } else {
+    RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat));
+    RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat));
+  }
+  P->cls_ld = feat_ld;
   ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
-  RET(add_conv(c, ops, c->pred, box_feat, 256, P->pred, 8, segs, op));
+  RET(add_conv(c, ops, c->pred, box_feat, feat_ld, P->pred, 8, segs, op));
   // geometry for the class-conditional 1x1 conv (weights arrive per call)
   {
     Geom g;
@@ -1054,6 +1080,27 @@ int sylph_finalize_weights(sylph_ctx* c) {
       RET(make_conv_bias(c, {hp + ".bbox_tower." + std::to_string(3 * i)}, &c->box_tower[i]));
       RET(make_gn(c, hp + ".bbox_tower." + std::to_string(3 * i + 1), &c->box_gn[i]));
     }
+    const char* pz = getenv("SYLPH_PAIR_TOWERS");
+    if (c->cfg.num_cls_convs == c->cfg.num_box_convs && c->cfg.num_cls_convs > 0 && !(pz && atoi(pz) == 0)) {
+      // run both towers as ONE launch per layer: outputs side by side ([rows][512] = cls | bbox)
+      const int n = c->cfg.num_cls_convs;
+      c->pair_tower.resize(n); c->pair_gn.resize(n);
+      for (int i = 0; i < n; ++i) {
+        RET(make_conv_bias(c, {hp + ".cls_tower." + std::to_string(3 * i), hp + ".bbox_tower." + std::to_string(3 * i)},
+                           &c->pair_tower[i]));
+        std::vector<float> ga, be;
+        for (const char* t : {".cls_tower.", ".bbox_tower."}) {
+          const HostTensor *g = find_w(c, hp + t + std::to_string(3 * i + 1) + ".weight"),
+                           *b = find_w(c, hp + t + std::to_string(3 * i + 1) + ".bias");
+          if (!g || !b || g->data.size() != 256) return fail("missing GroupNorm weights of the FCOS towers");
+          ga.insert(ga.end(), g->data.begin(), g->data.end());
+          be.insert(be.end(), b->data.begin(), b->data.end());
+        }
+        RET(upload_vec(c, &c->pair_gn[i].gamma, ga, 512));
+        RET(upload_vec(c, &c->pair_gn[i].beta, be, 512));
+      }
+      c->paired = true;
+    }
     RET(make_conv_bias(c, {hp + ".bbox_pred", hp + ".ctrness", hp + ".iou_overlap"}, &c->pred));
     c->level_scales.assign(c->cfg.nlevels, 1.f);
     if (c->cfg.use_scale)
@@ -1273,7 +1320,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   else { a.tiles = P->head_tiles; a.n_mtiles = P->head_mtiles; }
   a.n_ntiles = Npad / bn;
   a.Cin = 256; a.Cout = N; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
-  a.in_ld = 256; a.out_ld = Npad;
+  a.in_ld = P->cls_ld; a.out_ld = Npad;
   KCHK(timed_conv(c, c->dt, true, a, BM, bn, 2.0 * (double)rows * N * 256.0, c->stream), "cond_cls_logits");
   return 0;
 }
