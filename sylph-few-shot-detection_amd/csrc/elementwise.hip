@@ -237,17 +237,24 @@ __global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ 
     a[j] = st.y * gamma[g * 8 + j];
     b[j] = beta[g * 8 + j] - st.x * a[j];
   }
-  for (int r = r_begin + rl; r < r_end; r += rstep) {
-    T* p = x + (size_t)(sg.row0 + r) * ld + g * 8;
-    float v[8];
-    load8<T>(p, v);
+  // 4 independent rows per iteration: 4 x 16-byte loads in flight per lane (HBM-bound pass)
+  for (int r = r_begin + rl; r < r_end; r += 4 * rstep) {
+    float v[4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = fmaf(v[j], a[j], b[j]);
-      if (relu) t = t > 0.f ? t : 0.f;
-      v[j] = t;
+    for (int u = 0; u < 4; ++u)
+      if (r + u * rstep < r_end) load8<T>(x + (size_t)(sg.row0 + r + u * rstep) * ld + g * 8, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + u * rstep < r_end) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = fmaf(v[u][j], a[j], b[j]);
+          if (relu) t = t > 0.f ? t : 0.f;
+          v[u][j] = t;
+        }
+        store8<T>(x + (size_t)(sg.row0 + r + u * rstep) * ld + g * 8, v[u]);
+      }
     }
-    store8<T>(p, v);
   }
 }
 

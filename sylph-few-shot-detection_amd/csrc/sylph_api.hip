@@ -657,16 +657,25 @@ static int build_head(sylph_ctx* c, Plan* P) {
   void *cls_feat = nullptr, *box_feat = nullptr;
   int feat_ld = 256;
   if (c->paired) {
-    // tA|tB and tC|tD are used as two [rows][512] ping-pong buffers
-    const void* in = P->F;
-    int in_ld = 256;
-    void* out = P->tA;
-    for (size_t i = 0; i < c->pair_tower.size(); ++i) {
-      ConvOpts o; o.pad = 1;
-      if (i > 0) { o.group_cout = 256; o.group_in_off = 256; }
-      RET(add_conv_gn(c, ops, c->pair_tower[i], in, in_ld, out, segs, o, c->pair_gn[i], 1));
-      in = out; in_ld = 512;
-      out = (out == P->tA) ? P->tC : P->tA;
+    // tA|tB and tC|tD are used as two [rows][512] ping-pong buffers.  The towers run image-chunk by
+    // image-chunk (depth first): a chunk's [rows][512] layer output (~23 MB per 800x1344 image) is
+    // normalised and consumed by the next layer while it is still resident in the 256 MiB Infinity Cache.
+    int chunk_imgs = P->B;
+    if (const char* cz = getenv("SYLPH_HEAD_CHUNK")) chunk_imgs = atoi(cz) > 0 ? atoi(cz) : P->B;
+    const void* in = nullptr;
+    for (int b0 = 0; b0 < P->B; b0 += chunk_imgs) {
+      const int b1 = b0 + chunk_imgs < P->B ? b0 + chunk_imgs : P->B;
+      const std::vector<SegDesc> csegs(segs.begin() + (size_t)b0 * L, segs.begin() + (size_t)b1 * L);
+      in = P->F;
+      int in_ld = 256;
+      void* out = P->tA;
+      for (size_t i = 0; i < c->pair_tower.size(); ++i) {
+        ConvOpts o; o.pad = 1;
+        if (i > 0) { o.group_cout = 256; o.group_in_off = 256; }
+        RET(add_conv_gn(c, ops, c->pair_tower[i], in, in_ld, out, csegs, o, c->pair_gn[i], 1));
+        in = out; in_ld = 512;
+        out = (out == P->tA) ? P->tC : P->tA;
+      }
     }
     cls_feat = const_cast<void*>(in);
     box_feat = (char*)cls_feat + 256 * e;
