@@ -66,7 +66,7 @@ template <> struct Mma<float> {
 };
 
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : 1))) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -113,13 +113,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
 
   int abase[AR], abase2[AR];
   uint32_t amask[AR];
+  // Pointwise stride-1 convs (most launches; their tiles are short, so per-tile setup is a visible
+  // share of the instruction stream) address the input by output position: no div, no tap loop.
+  const bool pw_fast = ntaps == 1 && a.pad == 0 && a.stride == 1 && !a.stem && sd.in_W == sd.out_W;
+  const bool in2_direct = in2 && a.stride2 == 1 && sd.in2_W == sd.out_W;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int pos = tile.y + r0 + RS * i;
     const bool rv = pos < seg_rows;
-    const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+    int oy = 0, ox = 0;
+    if (!pw_fast || (in2 && !in2_direct)) { oy = pos / sd.out_W; ox = pos - oy * sd.out_W; }
     uint32_t m = 0;
-    if (a.stem) {
+    if (pw_fast) {
+      abase[i] = (sd.in_row0 + pos) * a.in_ld + cl * EPC;
+      m = rv ? 1u : 0u;
+    } else if (a.stem) {
       // ResNet stem (7x7 s2 p3 over a 4-channel-padded image): a K-slice is RPS kernel rows of an
       // 8-pixel window [2*ox-4, 2*ox+4) x 4 channels (window pixel 0 and channel 3 carry zero
       // weights), so every 16-byte chunk is PPC whole, aligned pixels of one input row.
@@ -135,15 +143,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
     } else {
       const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
       abase[i] = (sd.in_row0 + iy0 * sd.in_W + ix0) * a.in_ld + cl * EPC;
-      for (int t = 0; t < ntaps; ++t) {
-        const int kh = t / KW, kw = t - kh * KW;
-        const bool ok = rv && (unsigned)(iy0 + kh) < (unsigned)sd.in_H && (unsigned)(ix0 + kw) < (unsigned)sd.in_W;
-        m |= (ok ? 1u : 0u) << t;
-      }
+      uint32_t colm = 0;  // taps of one kernel row whose column is inside the image
+      for (int kx = 0; kx < KW; ++kx) colm |= ((unsigned)(ix0 + kx) < (unsigned)sd.in_W ? 1u : 0u) << kx;
+      int sh = 0;
+      for (int ky = 0; ky < a.KH; ++ky, sh += KW)
+        if ((unsigned)(iy0 + ky) < (unsigned)sd.in_H) m |= colm << sh;
+      if (!rv) m = 0;
     }
     amask[i] = m;
     if (in2) {
-      abase2[i] = (sd.in2_row0 + (oy * a.stride2) * sd.in2_W + ox * a.stride2) * a.in2_ld + cl * EPC;
+      abase2[i] = in2_direct ? (sd.in2_row0 + pos) * a.in2_ld + cl * EPC
+                             : (sd.in2_row0 + (oy * a.stride2) * sd.in2_W + ox * a.stride2) * a.in2_ld + cl * EPC;
       if (rv) amask[i] |= 1u << 31;
     }
   }
@@ -176,6 +186,42 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
     if (++cc == cpt && !second) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
   };
 
+  // Every HBM access of the block is issued up front so that the only exposed memory round trip is
+  // the first operand slice:
+  //  * residual tile via global_load_lds (narrow HBM-bound tiles): piece-major LDS image, piece q =
+  //    bytes [128q, 128q+128) of every row at 128-byte pitch, read back by the epilogue;
+  //  * per-channel scale/shift: one float4 per lane of the first BN/2 lanes, parked in LDS later.
+  constexpr int SCP = BN + 4;                 // fp32 pitch of the epilogue tile (+16 B: conflict-free b128 writes)
+  constexpr int SC_BYTES = WTM * SCP * 4;
+  constexpr int RES_OFF = (NBUF * STAGE > SC_BYTES) ? NBUF * STAGE : SC_BYTES;
+  constexpr int RES_PIECES = BN * (int)sizeof(T) / 128;
+  constexpr bool SS_IN_STAGE = NBUF * STAGE >= SC_BYTES + BN * 8;  // scale/shift fit behind the epilogue tile
+  const int ss_off = SS_IN_STAGE ? SC_BYTES : RES_OFF + (a.res_lds ? BM * BN * (int)sizeof(T) : 0);
+  float4 ssv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (BN <= 64 && a.ss_padded) {
+    if (tid < BN / 4) ssv = a.scale ? reinterpret_cast<const float4*>(a.scale)[nt * (BN / 4) + tid] : make_float4(1.f, 1.f, 1.f, 1.f);
+    else if (tid < BN / 2 && a.shift) ssv = reinterpret_cast<const float4*>(a.shift)[nt * (BN / 4) + tid - BN / 4];
+  }
+  if (a.res_lds) {
+    const T* __restrict__ resg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int pos = tile.y + r0 + RS * i;
+      int rp = pos;
+      if (a.res_mode == 2) {
+        const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+        rp = (oy >> 1) * sd.res_W + (ox >> 1);
+      }
+      const T* rowp = resg + (size_t)(sd.res_row0 + rp) * a.res_ld + nt * BN + c16 * EPC;
+#pragma unroll
+      for (int q = 0; q < RES_PIECES; ++q) {
+        const T* src = pos < seg_rows ? rowp + q * (128 / (int)sizeof(T)) : zero + c16 * EPC;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + RES_OFF + q * BM * 128 + (wave * 8 + i * RS) * 128),
+                                         16, 0, 0);
+      }
+    }
+  }
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -197,7 +243,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);  // D^T: a lane holds 4 consecutive channels
     }
   };
 
@@ -223,7 +269,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
   }
 
   // ---- fused epilogue ---------------------------------------------------------------------------
-  // One pass per wave-row: its waves park their accumulators in LDS as fp32 [WTM][BN] (aliasing the
+  // One pass per wave-row: its waves park their accumulators in LDS as fp32 [WTM][BN+4] (aliasing the
   // staging buffers; the K loop ended on a barrier), then every lane owns 8 consecutive channels of
   // one row: 16-byte residual loads, 16-byte (bf16) / 32-byte (fp32) stores, 256 B per 16 lanes.
   float* const sC = reinterpret_cast<float*>(smem);
@@ -236,11 +282,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
   const bool active = n0 < a.Cout;
   const bool vec = (n0 + 8 <= a.Cout) && ((a.out_ld & 7) == 0) && (a.res_mode == 0 || (a.res_ld & 7) == 0);
   float sc[8], sh[8];
+  if (BN <= 64 && a.ss_padded) {
+    if (tid < BN / 2) *reinterpret_cast<float4*>(smem + ss_off + tid * 16) = ssv;  // visible after the barrier below
+  } else {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const bool nv = n0 + e < a.Cout;
-    sc[e] = (nv && a.scale) ? a.scale[n0 + e] : 1.f;
-    sh[e] = (nv && a.shift) ? a.shift[n0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      const bool nv = n0 + e < a.Cout;
+      sc[e] = (nv && a.scale) ? a.scale[n0 + e] : 1.f;
+      sh[e] = (nv && a.shift) ? a.shift[n0 + e] : 0.f;
+    }
   }
   // GroupNorm(32 x 8 channels) statistics of the fp32 outputs, fused: a lane's 8 channels are exactly
   // one group; Chan/Welford running (count, mean, M2) per lane, combined in a fixed order below.
@@ -253,21 +303,27 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int col = wn * WTN + j * 32 + (lane & 31);
-            sC[row * BN + col] = acc[i][j][r];
+          for (int g = 0; g < 4; ++g) {
+            const int row = i * 32 + (lane & 31);
+            const int col = wn * WTN + j * 32 + 8 * g + 4 * (lane >> 5);
+            *reinterpret_cast<float4*>(sC + row * SCP + col) =
+                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
           }
     }
     __syncthreads();
+    if (p == 0 && BN <= 64 && a.ss_padded) {
+      const float* ssl = reinterpret_cast<const float*>(smem + ss_off);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = ssl[c8 * 8 + e]; sh[e] = ssl[BN + c8 * 8 + e]; }
+    }
     if (!active) continue;
     for (int rl = rr; rl < WTM; rl += RPP) {
       const int pos = tile.y + p * WTM + rl;
       if (pos >= seg_rows) break;
       float v[8];
       {
-        const float4 lo = *reinterpret_cast<const float4*>(sC + rl * BN + c8 * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(sC + rl * BN + c8 * 8 + 4);
+        const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       }
 #pragma unroll
@@ -279,7 +335,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
           rp = (oy >> 1) * sd.res_W + (ox >> 1);
         }
         const T* rptr = res + (size_t)(sd.res_row0 + rp) * a.res_ld + n0;
-        if (vec) {
+        if (a.res_lds) {
+          float rv[8];
+          const int row = p * WTM + rl, byte = c8 * 8 * (int)sizeof(T);
+          load8<T>(reinterpret_cast<const T*>(smem + RES_OFF + (byte >> 7) * BM * 128 + row * 128 + (byte & 127)), rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        } else if (vec) {
           float rv[8];
           load8<T>(rptr, rv);
 #pragma unroll
@@ -289,10 +351,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : 1)) void conv
             if (n0 + e < a.Cout) v[e] += Cvt<T>::to_f(rptr[e]);
         }
       }
+      if (a.mul_nch > 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (n0 + e < a.mul_nch) v[e] *= sd.mul;
-        if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < a.mul_nch) v[e] *= sd.mul;
+      }
+      if (a.relu_nch >= a.Cout) {  // channels past Cout are never stored
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (a.relu_nch > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
       if (a.gn_partial) {
         float s8 = 0.f;
@@ -345,8 +415,10 @@ template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  const size_t stage = (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * BN * 4;
-  const size_t lds = stage > epi ? stage : epi;
+  const size_t stage = (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
+  size_t lds = stage > epi ? stage : epi;
+  if (a.res_lds) lds += (size_t)BM * BN * sizeof(T);
+  if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
   if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), lds, s, a);
@@ -398,7 +470,13 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
   *BN = bn;
 }
 
-int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s) {
+int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hipStream_t s) {
+  ConvArgs a = a_in;
+  // stage the residual through LDS on the narrow (HBM-bound) tiles; measured 1.4 % slower (LDS occupancy 5 -> 4 blocks), so off; SYLPH_CONV_RES_LDS=1 enables
+  static const int res_lds_on = getenv("SYLPH_CONV_RES_LDS") ? atoi(getenv("SYLPH_CONV_RES_LDS")) : 0;
+  static const int ss_on = getenv("SYLPH_CONV_SS_LDS") ? atoi(getenv("SYLPH_CONV_SS_LDS")) : 1;
+  a.res_lds = (res_lds_on && a.res_mode != 0 && BN == 64 && a.Cout % 64 == 0 && (a.res_ld & 7) == 0) ? 1 : 0;
+  if (!ss_on || BN > 64) a.ss_padded = 0;  // the wide tiles are MFMA-bound and have no VGPRs to spare for the prefetch
   if (a.KH * a.KW > 31) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
   if (a.Cin % bk != 0) return -4;

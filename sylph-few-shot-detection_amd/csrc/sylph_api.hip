@@ -388,6 +388,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode;
   a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
   a.group_cout = o.group_cout; a.group_in_off = o.group_in_off;
+  a.ss_padded = 1;  // ConvLayer scale/shift are zero-padded to Cout_pad
   if (o.in2) {
     a.in2 = o.in2; a.in2_ld = o.in2_ld; a.Cin2 = o.Cin2; a.stride2 = o.stride2;
     a.Cin = L.Cin - o.Cin2;  // the packed weights hold both K ranges back to back

@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""Run ONE conv layer shape in a loop (for rocprofv3 --pmc passes).  Usage: pmc_layer.py <name-substring> [batch]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sylph-few-shot-detection_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from sylph_amd.engine import Engine  # noqa: E402
+
+LAYERS = {
+    "res2.conv3": (200, 336, 64, 256, 1, 1, 0, 1, 0),
+    "res2.conv1": (200, 336, 256, 64, 1, 1, 0, 0, 0),
+    "res3.conv3": (100, 168, 128, 512, 1, 1, 0, 1, 0),
+    "tower": (100, 168, 256, 256, 3, 1, 1, 0, 1),
+}
+name = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+H, W, ci, co, k, s, p, res, gn = LAYERS[name]
+eng = Engine(None, dtype="bf16")
+ms, tf = eng.bench_conv(B, H, W, ci, co, k, s, p, bool(res), True, bool(gn), iters=5)
+print(name, ms * 1e3, "us", tf, "TF")
