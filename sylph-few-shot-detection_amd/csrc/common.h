@@ -46,6 +46,7 @@ struct ConvArgs {
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
   float* gn_partial;          // optional [n_mtiles][Cout/8][3] per-tile GroupNorm partials (n, mean, M2)
   int res_lds;                // set by launch_conv: residual tile staged through LDS
+  int ss_padded_host;         // as given by the caller (ss_padded is cleared for wide tiles)
   int ss_padded;              // scale/shift arrays are padded to a multiple of the N tile (vector prefetch allowed)
   int stem;                   // ResNet-stem A loader (see conv_igemm.hip)
   int tap_dy;                 // input rows advanced per kernel-row tap (1; stem: rows per K-slice)

@@ -65,7 +65,7 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : 1))) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
@@ -284,13 +284,80 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   float sc[8], sh[8];
   if (BN <= 64 && a.ss_padded) {
     if (tid < BN / 2) *reinterpret_cast<float4*>(smem + ss_off + tid * 16) = ssv;  // visible after the barrier below
-  } else {
+  } else if (!FAST) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const bool nv = n0 + e < a.Cout;
       sc[e] = (nv && a.scale) ? a.scale[n0 + e] : 1.f;
       sh[e] = (nv && a.shift) ? a.shift[n0 + e] : 0.f;
     }
+  }
+  if constexpr (FAST) {
+    // Launch-time guarantees (launch_conv): Cout % BN == 0, 16-byte aligned rows, padded scale/shift, no
+    // per-segment Scale, no GroupNorm partials, ReLU on all channels or none.  The row loop is then
+    // branch-free apart from the residual mode: these short-K tiles are instruction-issue bound.
+    if (BN > 64) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 s4 = a.scale ? reinterpret_cast<const float4*>(a.scale + n0)[h] : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b4 = a.shift ? reinterpret_cast<const float4*>(a.shift + n0)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sc[4 * h] = s4.x; sc[4 * h + 1] = s4.y; sc[4 * h + 2] = s4.z; sc[4 * h + 3] = s4.w;
+        sh[4 * h] = b4.x; sh[4 * h + 1] = b4.y; sh[4 * h + 2] = b4.z; sh[4 * h + 3] = b4.w;
+      }
+    }
+    const bool relu = a.relu_nch > 0;
+    const T* __restrict__ resn = res + n0;
+    OutT* __restrict__ outn = out + (size_t)sd.out_row0 * a.out_ld + n0;
+#pragma unroll
+    for (int p = 0; p < WGM; ++p) {
+      if (p > 0) __syncthreads();
+      if (wm == p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(sC + (i * 32 + (lane & 31)) * SCP + wn * WTN + j * 32 + 8 * g + 4 * (lane >> 5)) =
+                  make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+      __syncthreads();
+      if (p == 0 && BN <= 64) {
+        const float* ssl = reinterpret_cast<const float*>(smem + ss_off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = ssl[c8 * 8 + e]; sh[e] = ssl[BN + c8 * 8 + e]; }
+      }
+#pragma unroll
+      for (int it = 0; it < (WTM + RPP - 1) / RPP; ++it) {
+        const int rl = rr + it * RPP;
+        const int pos = tile.y + p * WTM + rl;
+        if ((WTM % RPP == 0 || rl < WTM) && pos < seg_rows) {
+          float v[8];
+          const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+          if (a.res_mode != 0) {
+            int rp = pos;
+            if (a.res_mode == 2) {
+              const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+              rp = (oy >> 1) * sd.res_W + (ox >> 1);
+            }
+            float rv[8];
+            load8<T>(resn + (size_t)(sd.res_row0 + rp) * a.res_ld, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          store8<OutT>(outn + (size_t)pos * a.out_ld, v);
+        }
+      }
+    }
+    return;
   }
   // GroupNorm(32 x 8 channels) statistics of the fp32 outputs, fused: a lane's 8 channels are exactly
   // one group; Chan/Welford running (count, mean, M2) per lane, combined in a fixed order below.
@@ -411,7 +478,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF>
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
@@ -419,8 +486,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   size_t lds = stage > epi ? stage : epi;
   if (a.res_lds) lds += (size_t)BM * BN * sizeof(T);
   if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
-  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), lds, s, a);
   return (int)hipGetLastError();
 }
@@ -428,21 +495,28 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
 static int g_nbuf = 1;
 void conv_set_nbuf(int n) { g_nbuf = n == 2 ? 2 : 1; }
 
-template <typename T, typename OutT, int NBUF>
+template <typename T, typename OutT, int NBUF, bool FAST>
 static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
-  if (BM == 256 && BN == 128) return launch_cfg<T, OutT, 256, 128, 4, 2, NBUF>(a, s);
-  if (BM == 128 && BN == 256) return launch_cfg<T, OutT, 128, 256, 2, 4, NBUF>(a, s);
-  if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2, NBUF>(a, s);
-  if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2, NBUF>(a, s);
-  if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1, NBUF>(a, s);
-  if (BM == 64 && BN == 128) return launch_cfg<T, OutT, 64, 128, 2, 2, NBUF>(a, s);
-  if (BM == 64 && BN == 64) return launch_cfg<T, OutT, 64, 64, 2, 2, NBUF>(a, s);
+  if (BM == 256 && BN == 128) return launch_cfg<T, OutT, 256, 128, 4, 2, NBUF, FAST>(a, s);
+  if (BM == 128 && BN == 256) return launch_cfg<T, OutT, 128, 256, 2, 4, NBUF, FAST>(a, s);
+  if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2, NBUF, FAST>(a, s);
+  if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2, NBUF, FAST>(a, s);
+  if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1, NBUF, FAST>(a, s);
+  if (BM == 64 && BN == 128) return launch_cfg<T, OutT, 64, 128, 2, 2, NBUF, FAST>(a, s);
+  if (BM == 64 && BN == 64) return launch_cfg<T, OutT, 64, 64, 2, 2, NBUF, FAST>(a, s);
   return -1;
+}
+
+// FAST epilogue: see the kernel.  Only the production dtype (bf16 in, bf16 out, single stage) gets it.
+static bool fast_ok(const ConvArgs& a, int BN) {
+  static const int on = getenv("SYLPH_CONV_FAST") ? atoi(getenv("SYLPH_CONV_FAST")) : 1;
+  return on && a.ss_padded_host && (BN > 64 || a.ss_padded) && a.Cout % BN == 0 && (a.out_ld & 7) == 0 && (a.res_mode == 0 || (a.res_ld & 7) == 0) &&
+         !a.gn_partial && a.mul_nch == 0 && (a.relu_nch == 0 || a.relu_nch >= a.Cout);
 }
 
 template <typename T, typename OutT>
 static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
-  return g_nbuf == 2 ? launch_n<T, OutT, 2>(a, BM, BN, s) : launch_n<T, OutT, 1>(a, BM, BN, s);
+  return g_nbuf == 2 ? launch_n<T, OutT, 2, false>(a, BM, BN, s) : launch_n<T, OutT, 1, false>(a, BM, BN, s);
 }
 
 // Tile choice: widest N tile the layer fills (MFMA-bound 3x3 convs); HBM-bound pointwise convs
@@ -476,6 +550,7 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   static const int res_lds_on = getenv("SYLPH_CONV_RES_LDS") ? atoi(getenv("SYLPH_CONV_RES_LDS")) : 0;
   static const int ss_on = getenv("SYLPH_CONV_SS_LDS") ? atoi(getenv("SYLPH_CONV_SS_LDS")) : 1;
   a.res_lds = (res_lds_on && a.res_mode != 0 && BN == 64 && a.Cout % 64 == 0 && (a.res_ld & 7) == 0) ? 1 : 0;
+  a.ss_padded_host = a.ss_padded;
   if (!ss_on || BN > 64) a.ss_padded = 0;  // the wide tiles are MFMA-bound and have no VGPRs to spare for the prefetch
   if (a.KH * a.KW > 31) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
@@ -483,6 +558,7 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   if (a.in2 && (a.Cin2 % bk != 0 || a.KH * a.KW != 1)) return -6;
   if (!a.zeros) return -5;
   if (dt == DT_BF16) {
+    if (!out_f32 && g_nbuf == 1 && fast_ok(a, BN)) return launch_n<bf16_t, bf16_t, 1, true>(a, BM, BN, s);
     return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);
   }
   return launch_t<float, float>(a, BM, BN, s);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Instruction-mix PMC passes for one layer shape: tools/pmc_insts.sh <layer> <outdir>   (each pass under its own timeout)
+L=$1; OUT=$2; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+i=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA" \
+           "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_BUSY_CYCLES" \
+           "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  i=$((i+1))
+  timeout 120 rocprofv3 --pmc $set --kernel-trace -d $OUT/p$i -o p -- python tools/pmc_layer.py $L > $OUT/p$i.log 2>&1 || echo "pass $i failed/timeout"
+done
+python - <<PY
+import sqlite3, glob
+for f in sorted(glob.glob("$OUT/p*/p_results.db")):
+    db = sqlite3.connect(f)
+    rows = db.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like '%conv_igemm%'").fetchall()
+    agg = {}
+    for k, c, v in rows:
+        a = agg.setdefault(c, [0, 0.0]); a[0] += 1; a[1] += v
+    for c, a in agg.items():
+        print(f"{c:45s} per-launch {a[1]/a[0]:16.1f}  (n={a[0]})")
+PY
