@@ -45,6 +45,7 @@ struct ConvArgs {
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
   float* gn_partial;          // optional [n_mtiles][Cout/8][3] per-tile GroupNorm partials (n, mean, M2)
+  int dbg;                    // temporary experiment switches
   int res_lds;                // set by launch_conv: residual tile staged through LDS
   int ss_padded_host;         // as given by the caller (ss_padded is cleared for wide tiles)
   int ss_padded;              // scale/shift arrays are padded to a multiple of the N tile (vector prefetch allowed)
@@ -93,7 +94,10 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 // ---- launcher prototypes (one per translation unit) -----------------------------------------
 // conv_igemm.hip
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);
-void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
+void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN, bool pipe_ok = false);
+// conv_pipe.hip: 256x256 deep-pipelined variant (BM == BN == 256 selects it in launch_conv)
+bool conv_pipe_ok(DType dt, bool out_f32, const ConvArgs& a);
+int launch_conv_pipe(const ConvArgs& a, hipStream_t s);
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 
 }  // namespace sylph

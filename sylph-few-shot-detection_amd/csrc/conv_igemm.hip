@@ -66,7 +66,7 @@ template <> struct Mma<float> {
 };
 
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : 1))) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : (BM * BN >= 256 * 128 ? 2 : 1)))) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -183,6 +183,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 #pragma unroll
     for (int j = 0; j < BR; ++j)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + (bbase[j] + boff)), (lds_ptr_t)(dB + j * RS * 128), 16, 0, 0);
+    // K order: taps outer, channel slices inner.  (Slices outer / taps inner would re-read the same lines
+    // back to back, but every CU then hammers lines with equal (address >> 7) & 3 at the same time and the
+    // L2 channels camp: measured 10-20 % slower on the 3x3 layers.)
     if (++cc == cpt && !second) { cc = 0; ++tap; if (++kw == KW) { kw = 0; ++kh; } }
   };
 
@@ -497,8 +500,8 @@ void conv_set_nbuf(int n) { g_nbuf = n == 2 ? 2 : 1; }
 
 template <typename T, typename OutT, int NBUF, bool FAST>
 static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
-  if (BM == 256 && BN == 128) return launch_cfg<T, OutT, 256, 128, 4, 2, NBUF, FAST>(a, s);
-  if (BM == 128 && BN == 256) return launch_cfg<T, OutT, 128, 256, 2, 4, NBUF, FAST>(a, s);
+  if (BM == 256 && BN == 128) return launch_cfg<T, OutT, 256, 128, 2, 2, NBUF, FAST>(a, s);
+  if (BM == 128 && BN == 256) return launch_cfg<T, OutT, 128, 256, 2, 2, NBUF, FAST>(a, s);
   if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2, NBUF, FAST>(a, s);
   if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2, NBUF, FAST>(a, s);
   if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1, NBUF, FAST>(a, s);
@@ -522,7 +525,13 @@ static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
 // Tile choice: widest N tile the layer fills (MFMA-bound 3x3 convs); HBM-bound pointwise convs
 // prefer 128x64 (fewer registers -> more co-resident blocks -> more loads in flight: measured
 // 3-5 % faster on the bottleneck 1x1 layers); drop to BM=64 when the grid would not fill 256 CUs.
-void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
+void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN, bool pipe_ok) {
+  // MFMA-bound layers with at least two full rounds of 256x256 tiles go to the deep-pipelined kernel
+  static const int pipe_on = getenv("SYLPH_CONV_PIPE") ? atoi(getenv("SYLPH_CONV_PIPE")) : 1;
+  if (pipe_on && pipe_ok && ntaps > 1 && cout % 256 == 0 && (pipe_on == 2 || (long)((rows_total + 255) / 256) * (cout / 256) >= 512)) {
+    *BM = 256; *BN = 256;
+    return;
+  }
   int bn = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
   if (ntaps == 1 && bn == 128 && cout % 64 == 0) bn = 64;
   if (const char* f = getenv("SYLPH_CONV_FORCE_BN")) {  // tuning knob
@@ -552,6 +561,7 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   a.res_lds = (res_lds_on && a.res_mode != 0 && BN == 64 && a.Cout % 64 == 0 && (a.res_ld & 7) == 0) ? 1 : 0;
   a.ss_padded_host = a.ss_padded;
   if (!ss_on || BN > 64) a.ss_padded = 0;  // the wide tiles are MFMA-bound and have no VGPRs to spare for the prefetch
+  if (BM == 256 && BN == 256) return conv_pipe_ok(dt, out_f32, a) ? launch_conv_pipe(a, s) : -8;
   if (a.KH * a.KW > 31) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
   if (a.Cin % bk != 0) return -4;

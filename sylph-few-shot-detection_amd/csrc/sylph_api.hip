@@ -373,7 +373,10 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   long rows = 0;
   for (auto& s : segs) rows += (long)s.out_H * s.out_W;
   int BM, BN;
-  conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN);
+  const int cout_l = o.cout_override >= 0 ? o.cout_override : L.Cout;
+  const bool pipe_ok = c->dt == DT_BF16 && !o.out_f32 && !o.stem && !o.in2 && !o.res && o.res_mode == 0 && o.mul_nch == 0 &&
+                       o.cout_override < 0 && (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0;
+  conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN, pipe_ok);
   if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
   Geom g;
   RET(make_geom(c, segs, BM, &g));
