@@ -47,12 +47,17 @@ constexpr int NSTAGE = 4;
 constexpr int SCP = PBN + 4;          // fp32 pitch of the epilogue tile
 
 
+#ifdef PIPE_NO_SCHED_FENCE
+#define PIPE_SCHED_FENCE
+#else
+#define PIPE_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
 #define SYLPH_BAR()                                \
   do {                                             \
     asm volatile("" ::: "memory");                 \
-    __builtin_amdgcn_sched_barrier(0);             \
+    PIPE_SCHED_FENCE;                              \
     __builtin_amdgcn_s_barrier();                  \
-    __builtin_amdgcn_sched_barrier(0);             \
+    PIPE_SCHED_FENCE;                              \
     asm volatile("" ::: "memory");                 \
   } while (0)
 
@@ -173,7 +178,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_pipe_kernel(const ConvArgs a) {
   // shadow: the wave is parked on the matrix pipe between MFMAs anyway.  Straight-line code: every
   // scalar branch here costs the matrix pipe an instruction-fetch bubble.
   auto mma = [&](int stage, bool valid) {
+#ifndef PIPE_NO_PRIO
     __builtin_amdgcn_s_setprio(1);
+#endif
     int n = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -186,7 +193,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_pipe_kernel(const ConvArgs a) {
           ++n;
         }
     advance();
+#ifndef PIPE_NO_PRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // ---- prologue: phases 0..2 in flight (phase q+3 is issued during M(q)) -------------------------------

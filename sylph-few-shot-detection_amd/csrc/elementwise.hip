@@ -9,6 +9,8 @@
 //   relu_rows   : the F.relu(p6) feeding P7 in AdelaiDet LastLevelP6P7
 //   GroupNorm   : nn.GroupNorm(32, C) in sylph/modeling/meta_fcos/fcos.py:97-98 and
 //                 sylph/modeling/code_generator/code_generator.py:648-688 (build_fpn_norm "GN")
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -262,7 +264,7 @@ int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg
                              const float* partial, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s) {
   if (ngroups != 32 && ngroups != 64) return -1;
-  const int rpc = GN_ROWS_PER_CHUNK;
+  static const int rpc = getenv("SYLPH_GN_RPC") ? atoi(getenv("SYLPH_GN_RPC")) : GN_ROWS_PER_CHUNK;
   dim3 grid((max_rows + rpc - 1) / rpc, nseg), block(256);
   if (dt == DT_BF16)
     hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, ngroups, rpc, partial,

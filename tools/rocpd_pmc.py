@@ -18,7 +18,7 @@ def last_step(dbfile, counter):
                       (counter,)).fetchall()
     idx = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]][-1]
     step = rows[idx:]
-    conv = [r for r in step if "conv_igemm_kernel" in r[0]]
+    conv = [r for r in step if "conv_igemm_kernel" in r[0] or "conv_pipe_kernel" in r[0]]
     pre = step[0][1]
     return sum(r[1] for r in conv) * 1024.0, len(conv), pre * 1024.0
 
