@@ -1,0 +1,38 @@
+"""conv_pipe_kernel (256x256 deep-pipelined conv) parity.  The kernel is picked automatically only for launches
+with >= 512 tiles, so: (1) a conv large enough to select it is compared with torch, and (2) the head / episode
+parity tests are re-run in a subprocess with SYLPH_CONV_PIPE=2, which forces it for every eligible layer (the
+paired FCOS towers with their fused GroupNorm statistics, FPN output convs) at the small golden sizes."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", [(2, 64, 256, 256, 256, 1), (2, 128, 250, 270, 256, 1), (3, 64, 300, 310, 512, 2)])
+def test_large_conv_selects_pipe_kernel_and_matches_torch(case):
+    from sylph_amd.engine import Engine
+    B, C, H, W, Cout, stride = case
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 0.5).bfloat16().float()
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (C * 9) ** 0.5).bfloat16().float()
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    eng = Engine(None, dtype="bf16")
+    y = eng.conv2d(x, w, scale, shift, stride, 1, True)
+    ref = F.relu(F.conv2d(x.cuda(), w.cuda(), None, stride, 1) * scale.cuda().view(1, -1, 1, 1) + shift.cuda().view(1, -1, 1, 1))
+    err = (y - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), f"max err {err}"
+
+
+def test_head_and_episode_parity_with_pipe_kernel_forced():
+    env = dict(os.environ, SYLPH_CONV_PIPE="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_parity.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "head or episode or backbone or codegen or full"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
