@@ -45,7 +45,7 @@ struct ConvArgs {
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
   float* gn_partial;          // optional [n_mtiles][Cout/8][3] per-tile GroupNorm partials (n, mean, M2)
-  int dbg;                    // temporary experiment switches
+  int halo;                   // 3x3 s1 p1 halo-tile mode: tiles[].y = (patch row << 16) | patch col (8 x 16 patches)
   int res_lds;                // set by launch_conv: residual tile staged through LDS
   int ss_padded_host;         // as given by the caller (ss_padded is cleared for wide tiles)
   int ss_padded;              // scale/shift arrays are padded to a multiple of the N tile (vector prefetch allowed)

@@ -65,8 +65,8 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : (BM * BN >= 256 * 128 ? 2 : 1)))) void conv_igemm_kernel(const ConvArgs a) {
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO>
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : (BM * BN >= 256 * 128 ? 2 : (BM * BN == 128 * 128 ? 4 : 1))))) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   constexpr int NT = WGM * WGN * 64;         // threads per block (4 or 8 waves)
   constexpr int RS = NT / 8;                 // tile rows staged by one load instruction of the whole block
   constexpr int AR = BM / RS, BR = BN / RS;  // wave-level loads per slice (8 rows each)
-  constexpr int STAGE = (BM + BN) * 128;
+  // HALO (3x3 s1 p1): the M tile is an 8 x 16 patch of output positions; its 10 x 18 input halo (192 LDS rows with the
+  // tail of the last load round) is loaded ONCE per 64-channel slice and the 9 taps read shifted rows of it.
+  constexpr int HPW = 16, HPH = BM / HPW, HW2 = HPW + 2, HROWS = (HPH + 2) * HW2, HRND = (HROWS + NT / 8 - 1) / (NT / 8);
+  constexpr int STAGE = HALO ? (BN + HRND * (NT / 8)) * 128 : (BM + BN) * 128;
+  static_assert(!HALO || (NBUF == 1 && BM == 128 && NT == 256), "halo mode: 128-row tiles, single stage");
   static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   const int2 tile = a.tiles[mt];
   const SegDesc sd = a.segs[tile.x];
   const int seg_rows = sd.out_H * sd.out_W;
+  const int oy0 = HALO ? (tile.y >> 16) : 0, ox0 = HALO ? (tile.y & 0xffff) : 0;  // HALO: tile.y packs the patch origin
 
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
   const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   const bool pw_fast = ntaps == 1 && a.pad == 0 && a.stride == 1 && !a.stem && sd.in_W == sd.out_W;
   const bool in2_direct = in2 && a.stride2 == 1 && sd.in2_W == sd.out_W;
 #pragma unroll
-  for (int i = 0; i < AR; ++i) {
+  for (int i = 0; i < (HALO ? 0 : AR); ++i) {
     const int pos = tile.y + r0 + RS * i;
     const bool rv = pos < seg_rows;
     int oy = 0, ox = 0;
@@ -157,6 +162,28 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
       if (rv) amask[i] |= 1u << 31;
     }
   }
+  // HALO: source of LDS halo row t*32 + r0 (input position (oy0-1+hy, ox0-1+hx)); rows outside the image, and the
+  // tail rows past the 10 x 18 halo, come from the zero page.
+  int hsrc[HRND];
+  uint32_t hmask = 0;
+  int hb[TM];
+  if constexpr (HALO) {
+    const int goff_h = a.group_cout > 0 ? ((nt * BN) / a.group_cout) * a.group_in_off : 0;
+#pragma unroll
+    for (int t = 0; t < HRND; ++t) {
+      const int hrow = t * RS + r0;
+      const int hy = hrow / HW2, hx = hrow - hy * HW2;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)sd.in_H && (unsigned)ix < (unsigned)sd.in_W;
+      hsrc[t] = (sd.in_row0 + iy * sd.in_W + ix) * a.in_ld + cl * EPC + goff_h;
+      hmask |= (ok ? 1u : 0u) << t;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = wm * WTM + i * 32 + (lane & 31);
+      hb[i] = (m / HPW) * HW2 + (m % HPW);
+    }
+  }
   if (a.group_cout > 0) {  // grouped conv: this N tile's group reads its own input-channel window
     const int goff = ((nt * BN) / a.group_cout) * a.group_in_off;
 #pragma unroll
@@ -168,6 +195,26 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 
   int tap = 0, cc = 0, kh = 0, kw = 0;  // state of the NEXT slice to fetch
   auto issue = [&](int buf) {
+    if constexpr (HALO) {
+      // LDS: [B tile][halo].  Slice order: 64-channel slice outer, taps inner; the halo is fetched on tap 0.
+      char* dBh = smem + wave * 8 * 128;
+      char* dH = dBh + BN * 128;
+      if (tap == 0) {
+#pragma unroll
+        for (int t = 0; t < HRND; ++t) {
+          const T* src = ((hmask >> t) & 1u) ? in + (hsrc[t] + cc * BK) : zero + cl * EPC;
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dH + t * RS * 128), 16, 0, 0);
+        }
+      }
+      const int boff = tap * Cin + cc * BK;
+#pragma unroll
+      for (int j = 0; j < BR; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wt + (bbase[j] + boff)), (lds_ptr_t)(dBh + j * RS * 128), 16, 0, 0);
+      ++tap;
+      if (++kw == KW) { kw = 0; ++kh; }
+      if (tap == ntaps) { tap = 0; kh = 0; kw = 0; ++cc; }
+      return;
+    }
     char* dA = smem + buf * STAGE + wave * 8 * 128;  // wave-uniform: lane l lands at +16*l
     char* dB = dA + BM * 128;
     const bool second = tap >= ntaps;  // only in dual-source mode
@@ -233,14 +280,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int buf) {
-    const char* tA = smem + buf * STAGE;
-    const char* tB = tA + BM * 128;
+  auto compute = [&](int buf, int hoff) {
+    const char* tA = HALO ? smem + BN * 128 : smem + buf * STAGE;
+    const char* tB = HALO ? smem : tA + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
       typename Mma<T>::frag_t fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = Mma<T>::load(tA, wm * WTM + i * 32 + (lane & 31), ks, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = Mma<T>::load(tA, HALO ? hb[i] + hoff : wm * WTM + i * 32 + (lane & 31), ks, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = Mma<T>::load(tB, wn * WTN + j * 32 + (lane & 31), ks, lane);
 #pragma unroll
@@ -252,10 +299,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 
   if (NBUF == 1) {
     for (int kt = 0; kt < nk; ++kt) {
+      const int hoff = kh * HW2 + kw;  // halo row offset of the tap about to be fetched / computed
       issue(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      compute(0);
+      compute(0, hoff);
       __syncthreads();
     }
   } else {
@@ -265,7 +313,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nk) issue(buf ^ 1);
-      compute(buf);
+      compute(buf, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -333,8 +381,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 #pragma unroll
       for (int it = 0; it < (WTM + RPP - 1) / RPP; ++it) {
         const int rl = rr + it * RPP;
-        const int pos = tile.y + p * WTM + rl;
-        if ((WTM % RPP == 0 || rl < WTM) && pos < seg_rows) {
+        int pos = tile.y + p * WTM + rl;
+        bool pv = pos < seg_rows;
+        if constexpr (HALO) {
+          const int m = p * WTM + rl, oy = oy0 + m / HPW, ox = ox0 + m % HPW;
+          pos = oy * sd.out_W + ox;
+          pv = oy < sd.out_H && ox < sd.out_W;
+        }
+        if ((WTM % RPP == 0 || rl < WTM) && pv) {
           float v[8];
           const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
           const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
@@ -388,8 +442,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     }
     if (!active) continue;
     for (int rl = rr; rl < WTM; rl += RPP) {
-      const int pos = tile.y + p * WTM + rl;
-      if (pos >= seg_rows) break;
+      int pos = tile.y + p * WTM + rl;
+      if constexpr (HALO) {
+        const int m = p * WTM + rl, oy = oy0 + m / HPW, ox = ox0 + m % HPW;
+        if (oy >= sd.out_H || ox >= sd.out_W) continue;
+        pos = oy * sd.out_W + ox;
+      } else {
+        if (pos >= seg_rows) break;
+      }
       float v[8];
       {
         const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
@@ -481,16 +541,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST>
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  const size_t stage = (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
+  const size_t stage = HALO ? (size_t)(BN + 192) * 128 : (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
   size_t lds = stage > epi ? stage : epi;
   if (a.res_lds) lds += (size_t)BM * BN * sizeof(T);
   if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
-  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO>;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), lds, s, a);
   return (int)hipGetLastError();
 }
@@ -526,9 +586,14 @@ static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
 // prefer 128x64 (fewer registers -> more co-resident blocks -> more loads in flight: measured
 // 3-5 % faster on the bottleneck 1x1 layers); drop to BM=64 when the grid would not fill 256 CUs.
 void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN, bool pipe_ok) {
-  // MFMA-bound layers with at least two full rounds of 256x256 tiles go to the deep-pipelined kernel
-  static const int pipe_on = getenv("SYLPH_CONV_PIPE") ? atoi(getenv("SYLPH_CONV_PIPE")) : 1;
-  if (pipe_on && pipe_ok && ntaps > 1 && cout % 256 == 0 && (pipe_on == 2 || (long)((rows_total + 255) / 256) * (cout / 256) >= 512)) {
+  // MFMA-bound layers go to the deep-pipelined 256x256 kernel (one block per CU) when its rounds fill: at
+  // least two rounds over the 256 CUs and >= 80 % of the last one used (res4.conv2 at B=32: 525 tiles =
+  // 2.05 rounds -> 3 rounds at 68 %: measured 223 us vs 203 us for the 128x128 kernel).
+  static const int pipe_on = getenv("SYLPH_CONV_PIPE") ? atoi(getenv("SYLPH_CONV_PIPE")) : 0;  // off: the halo-tile mode of conv_igemm is faster end to end (1454 vs 1439 img/s)
+  const long ptiles = (long)((rows_total + 255) / 256) * (cout / 256);
+  const long prounds = (ptiles + 255) / 256;
+  if (pipe_on && pipe_ok && ntaps > 1 && cout % 256 == 0 &&
+      (pipe_on == 2 || (ptiles >= 512 && ptiles * 10 >= prounds * 256 * 8))) {
     *BM = 256; *BN = 256;
     return;
   }
@@ -568,6 +633,15 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   if (a.in2 && (a.Cin2 % bk != 0 || a.KH * a.KW != 1)) return -6;
   if (!a.zeros) return -5;
   if (dt == DT_BF16) {
+    if (a.halo) {  // 3x3 s1 p1 with patch tiles (sylph_api.hip builds the matching tile table)
+      if (out_f32 || g_nbuf != 1 || BM != 128 || (BN != 128 && BN != 64) || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 ||
+          a.stem || a.in2) return -9;
+      const bool fast = fast_ok(a, BN);
+      if (BN == 128) return fast ? launch_cfg<bf16_t, bf16_t, 128, 128, 2, 2, 1, true, true>(a, s)
+                                 : launch_cfg<bf16_t, bf16_t, 128, 128, 2, 2, 1, false, true>(a, s);
+      return fast ? launch_cfg<bf16_t, bf16_t, 128, 64, 2, 2, 1, true, true>(a, s)
+                  : launch_cfg<bf16_t, bf16_t, 128, 64, 2, 2, 1, false, true>(a, s);
+    }
     if (!out_f32 && g_nbuf == 1 && fast_ok(a, BN)) return launch_n<bf16_t, bf16_t, 1, true>(a, BM, BN, s);
     return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);
   }

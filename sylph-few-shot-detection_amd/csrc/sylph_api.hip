@@ -334,6 +334,24 @@ static int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geo
   return 0;
 }
 
+// 3x3 s1 p1 halo mode (conv_igemm.hip HALO): M tiles are 8 x 16 patches of one segment, tile.y = (row << 16) | col
+static int make_geom_patch(sylph_ctx* c, const std::vector<SegDesc>& segs, Geom* g) {
+  std::vector<int2> tiles;
+  for (size_t s = 0; s < segs.size(); ++s) {
+    const int t0 = (int)tiles.size();
+    for (int y = 0; y < segs[s].out_H; y += 8)
+      for (int x = 0; x < segs[s].out_W; x += 16) tiles.push_back(make_int2((int)s, (y << 16) | x));
+    g->seg_tiles.push_back(make_int2(t0, (int)tiles.size() - t0));
+  }
+  void *ds = nullptr, *dtl = nullptr;
+  RET(upload(c, &ds, segs.data(), segs.size() * sizeof(SegDesc)));
+  RET(upload(c, &dtl, tiles.data(), tiles.size() * sizeof(int2)));
+  g->segs = (const SegDesc*)ds;
+  g->tiles = (const int2*)dtl;
+  g->n_mtiles = (int)tiles.size();
+  return 0;
+}
+
 // launch the conv kernel, optionally bracketed by HIP events on the same stream
 static int timed_conv(sylph_ctx* c, DType dt, bool of32, const ConvArgs& a, int BM, int BN, double flops,
                       hipStream_t s) {
@@ -378,10 +396,21 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
                        o.cout_override < 0 && (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0;
   conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN, pipe_ok);
   if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
+  // 3x3 stride-1 convs on 128-row tiles: halo mode (input patch staged once per channel slice, 9 taps read it)
+  static const int halo_on = getenv("SYLPH_CONV_HALO") ? atoi(getenv("SYLPH_CONV_HALO")) : 1;
+  bool halo = halo_on && c->dt == DT_BF16 && !o.out_f32 && BM == 128 && (BN == 128 || BN == 64) && L.KH == 3 && L.KW == 3 &&
+              o.stride == 1 && o.pad == 1 && !o.stem && !o.in2 && L.Cin % 64 == 0;
+  if (halo) {  // patches must not waste much of the launch on ragged edges (tiny pyramid levels are cheap anyway)
+    long patch_rows = 0;
+    for (auto& sg : segs) patch_rows += (long)((sg.out_H + 7) / 8) * ((sg.out_W + 15) / 16) * 128;
+    if (halo_on != 2 && patch_rows * 10 > rows * 13) halo = false;
+  }
   Geom g;
-  RET(make_geom(c, segs, BM, &g));
+  if (halo) RET(make_geom_patch(c, segs, &g));
+  else RET(make_geom(c, segs, BM, &g));
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.halo = halo ? 1 : 0;
   a.in = in; a.wt = L.w; a.out = out; a.res = o.res;
   a.scale = L.scale; a.shift = L.shift; a.zeros = c->zeros;
   a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;
