@@ -417,8 +417,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     return;
   }
   // GroupNorm(32 x 8 channels) statistics of the fp32 outputs, fused: a lane's 8 channels are exactly
-  // one group; Chan/Welford running (count, mean, M2) per lane, combined in a fixed order below.
-  float gn_n = 0.f, gn_mean = 0.f, gn_m2 = 0.f;
+  // one group; per-lane shifted sums -> (count, mean, M2), combined (Chan) in a fixed order below.
+  float gn_n = 0.f, gn_pv = 0.f, gn_s1 = 0.f, gn_s2 = 0.f;
   for (int p = 0; p < WGM; ++p) {
     if (p > 0) __syncthreads();
     if (wm == p) {
@@ -494,18 +494,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
         for (int e = 0; e < 8; ++e)
           if (n0 + e < a.relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
-      if (a.gn_partial) {
-        float s8 = 0.f;
+      if (a.gn_partial) {  // shifted sums about the lane's first row mean (fp32-exact enough, no divisions)
+        if (gn_n == 0.f) gn_pv = 0.125f * (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s8 += v[e];
-        const float m8 = s8 * 0.125f;
-        float q8 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[e] - m8; q8 = fmaf(d, d, q8); }
-        const float nn = gn_n + 8.f, delta = m8 - gn_mean;
-        gn_mean += delta * (8.f / nn);
-        gn_m2 += q8 + delta * delta * (gn_n * 8.f / nn);
-        gn_n = nn;
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - gn_pv; gn_s1 += d; gn_s2 = fmaf(d, d, gn_s2); }
+        gn_n += 8.f;
       }
       OutT* optr = out + (size_t)(sd.out_row0 + pos) * a.out_ld + n0;
       if (vec) {
@@ -519,9 +512,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   if (a.gn_partial) {
     __syncthreads();
     float* red = sC;  // [RPP][TPR][3]
+    const float inv_n = gn_n > 0.f ? 1.f / gn_n : 0.f;
     red[(rr * TPR + c8) * 3 + 0] = gn_n;
-    red[(rr * TPR + c8) * 3 + 1] = gn_mean;
-    red[(rr * TPR + c8) * 3 + 2] = gn_m2;
+    red[(rr * TPR + c8) * 3 + 1] = gn_pv + gn_s1 * inv_n;          // lane mean
+    red[(rr * TPR + c8) * 3 + 2] = gn_s2 - gn_s1 * gn_s1 * inv_n;  // lane M2
     __syncthreads();
     if (rr == 0 && active) {
       float N = 0.f, M = 0.f, Q = 0.f;

@@ -203,24 +203,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
 // Fused variant: the conv epilogue already left (n, mean, M2) per (M-tile, group); every block folds
 // the partials of its segment in tile order (deterministic, fp64) and applies the affine (+ReLU).
 // ngroups = C/8 (32 for one tower, 64 for the paired cls|bbox towers held side by side).
-template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ x, const GnSeg* segs, int ld, int ngroups,
-                                                                int rows_per_chunk,
-                                                                const float* __restrict__ partial, float eps,
-                                                                const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, int relu) {
-  const int seg = blockIdx.y, chunk = blockIdx.x;
-  const GnSeg sg = segs[seg];
-  const int r_begin = chunk * rows_per_chunk;
-  if (r_begin >= sg.nrows) return;
-  const int r_end = min(sg.nrows, r_begin + rows_per_chunk);
-  const int g = threadIdx.x % ngroups, rl = threadIdx.x / ngroups, rstep = 256 / ngroups;
-  __shared__ float2 st_sh[64];
-  if ((int)threadIdx.x < ngroups) {
-    double N = 0.0, M = 0.0, Q = 0.0;
-    for (int t = 0; t < sg.ntiles; ++t) {
-      const float* p = partial + ((size_t)(sg.tile0 + t) * ngroups + g) * 3;
-      const double nb = p[0], mb = p[1], qb = p[2];
+// Finalize: one block per segment folds the conv epilogue's per-tile (n, mean, M2) partials of every group in a
+// fixed order (fp64 Chan merges: 256/ngroups interleaved chains per group, then the chains in index order) and
+// leaves (mean, rstd) per (segment, group).  Done once per layer: the fp64 chain (two divisions per tile) is far
+// too slow to repeat in every block of the streaming pass.
+__global__ __launch_bounds__(256) void gn_finalize_partials_kernel(const GnSeg* segs, int ngroups, const float* __restrict__ partial,
+                                                                   float eps, float2* __restrict__ stats) {
+  const GnSeg sg = segs[blockIdx.x];
+  const int g = threadIdx.x % ngroups, sub = threadIdx.x / ngroups, nsub = 256 / ngroups;
+  __shared__ double sh[256 * 3];
+  double N = 0.0, M = 0.0, Q = 0.0;
+  for (int t = sub; t < sg.ntiles; t += nsub) {
+    const float* p = partial + ((size_t)(sg.tile0 + t) * ngroups + g) * 3;
+    const double nb = p[0], mb = p[1], qb = p[2];
+    if (nb > 0.0) {
+      const double nn = N + nb, delta = mb - M;
+      M += delta * (nb / nn);
+      Q += qb + delta * delta * (N * nb / nn);
+      N = nn;
+    }
+  }
+  sh[threadIdx.x * 3 + 0] = N; sh[threadIdx.x * 3 + 1] = M; sh[threadIdx.x * 3 + 2] = Q;
+  __syncthreads();
+  if (sub == 0) {
+    for (int u = 1; u < nsub; ++u) {
+      const double nb = sh[(u * ngroups + g) * 3 + 0], mb = sh[(u * ngroups + g) * 3 + 1], qb = sh[(u * ngroups + g) * 3 + 2];
       if (nb > 0.0) {
         const double nn = N + nb, delta = mb - M;
         M += delta * (nb / nn);
@@ -229,10 +236,22 @@ __global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ 
       }
     }
     const double var = N > 0.0 ? Q / N : 0.0;
-    st_sh[g] = make_float2((float)M, (float)(1.0 / sqrt(var + (double)eps)));
+    stats[(size_t)blockIdx.x * ngroups + g] = make_float2((float)M, (float)(1.0 / sqrt(var + (double)eps)));
   }
-  __syncthreads();
-  const float2 st = st_sh[g];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ x, const GnSeg* segs, int ld, int ngroups,
+                                                                int rows_per_chunk, const float2* __restrict__ stats,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int relu) {
+  const int seg = blockIdx.y, chunk = blockIdx.x;
+  const GnSeg sg = segs[seg];
+  const int r_begin = chunk * rows_per_chunk;
+  if (r_begin >= sg.nrows) return;
+  const int r_end = min(sg.nrows, r_begin + rows_per_chunk);
+  const int g = threadIdx.x % ngroups, rl = threadIdx.x / ngroups, rstep = 256 / ngroups;
+  const float2 st = stats[(size_t)seg * ngroups + g];
   float a[8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -261,17 +280,18 @@ __global__ __launch_bounds__(256) void gn_apply_partials_kernel(T* __restrict__ 
 }
 
 int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg* segs_dev, int nseg, int max_rows,
-                             const float* partial, const float* gamma, const float* beta, float eps, int relu,
+                             const float* partial, float2* stats_ws, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s) {
   if (ngroups != 32 && ngroups != 64) return -1;
-  static const int rpc = getenv("SYLPH_GN_RPC") ? atoi(getenv("SYLPH_GN_RPC")) : GN_ROWS_PER_CHUNK;
+  const int rpc = GN_ROWS_PER_CHUNK;
+  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(256), 0, s, segs_dev, ngroups, partial, eps, stats_ws);
   dim3 grid((max_rows + rpc - 1) / rpc, nseg), block(256);
   if (dt == DT_BF16)
-    hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, ngroups, rpc, partial,
-                       eps, gamma, beta, relu);
+    hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, ngroups, rpc, stats_ws, gamma,
+                       beta, relu);
   else
-    hipLaunchKernelGGL(gn_apply_partials_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, ngroups, rpc, partial,
-                       eps, gamma, beta, relu);
+    hipLaunchKernelGGL(gn_apply_partials_kernel<float>, grid, block, 0, s, (float*)x, segs_dev, ld, ngroups, rpc, stats_ws, gamma,
+                       beta, relu);
   return (int)hipGetLastError();
 }
 

@@ -66,7 +66,7 @@ int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s);
 int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg* segs_dev, int nseg, int max_rows,
-                             const float* partial, const float* gamma, const float* beta, float eps, int relu,
+                             const float* partial, float2* stats_ws, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s);
 int launch_fill_random(DType dt, void* p, size_t n, unsigned seed, hipStream_t s);
 struct CopySeg { int src_row0, dst_row0, nrows; };

@@ -457,8 +457,10 @@ static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L,
   const DType dt = c->dt;
   const int nseg = (int)gs.size();
   const float *ga = G.gamma, *be = G.beta;
+  float2* stats_ws = nullptr;
+  RET(c->dalloc((void**)&stats_ws, (size_t)nseg * ngroups * sizeof(float2)));
   ops.push_back([=](hipStream_t s) {
-    return launch_gn_apply_partials(dt, out, ld, ngroups, gsd, nseg, max_rows, partial, ga, be, 1e-5f, relu, s);
+    return launch_gn_apply_partials(dt, out, ld, ngroups, gsd, nseg, max_rows, partial, stats_ws, ga, be, 1e-5f, relu, s);
   });
   return 0;
 }
