@@ -628,8 +628,12 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   if (!a.zeros) return -5;
   if (dt == DT_BF16) {
     if (a.halo) {  // 3x3 s1 p1 with patch tiles (sylph_api.hip builds the matching tile table)
-      if (out_f32 || g_nbuf != 1 || BM != 128 || (BN != 128 && BN != 64) || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 ||
-          a.stem || a.in2) return -9;
+      if (g_nbuf != 1 || BM != 128 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.stem || a.in2) return -9;
+      if (BN == 32) {  // narrow prediction convs (bbox/ctrness, code-generator heads): fp32 or bf16 out
+        return out_f32 ? launch_cfg<bf16_t, float, 128, 32, 4, 1, 1, false, true>(a, s)
+                       : launch_cfg<bf16_t, bf16_t, 128, 32, 4, 1, 1, false, true>(a, s);
+      }
+      if (out_f32 || (BN != 128 && BN != 64)) return -9;
       const bool fast = fast_ok(a, BN);
       if (BN == 128) return fast ? launch_cfg<bf16_t, bf16_t, 128, 128, 2, 2, 1, true, true>(a, s)
                                  : launch_cfg<bf16_t, bf16_t, 128, 128, 2, 2, 1, false, true>(a, s);

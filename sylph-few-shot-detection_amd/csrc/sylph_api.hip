@@ -398,7 +398,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
   // 3x3 stride-1 convs on 128-row tiles: halo mode (input patch staged once per channel slice, 9 taps read it)
   static const int halo_on = getenv("SYLPH_CONV_HALO") ? atoi(getenv("SYLPH_CONV_HALO")) : 1;
-  bool halo = halo_on && c->dt == DT_BF16 && !o.out_f32 && BM == 128 && (BN == 128 || BN == 64) && L.KH == 3 && L.KW == 3 &&
+  bool halo = halo_on && c->dt == DT_BF16 && BM == 128 && (BN == 32 || (!o.out_f32 && (BN == 128 || BN == 64))) && L.KH == 3 && L.KW == 3 &&
               o.stride == 1 && o.pad == 1 && !o.stem && !o.in2 && L.Cin % 64 == 0;
   if (halo) {  // patches must not waste much of the launch on ragged edges (tiny pyramid levels are cheap anyway)
     long patch_rows = 0;
