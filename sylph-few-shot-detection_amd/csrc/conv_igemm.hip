@@ -47,6 +47,9 @@ template <> struct Mma<bf16_t> {
     const int sw = chunk ^ ((row >> 1) & 7);
     return *reinterpret_cast<const frag_t*>(tile + row * 128 + sw * 16);
   }
+  static __device__ __forceinline__ frag_t load_sw(const char* tile, int row, int ks, int lane, int swz) {
+    return *reinterpret_cast<const frag_t*>(tile + row * 128 + ((ks * 2 + (lane >> 5)) ^ swz) * 16);
+  }
   static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
@@ -59,6 +62,10 @@ template <> struct Mma<float> {
     const int k = ks * 2 + (lane >> 5);
     const int sw = (k >> 2) ^ ((row >> 1) & 7);
     return *reinterpret_cast<const float*>(tile + row * 128 + sw * 16 + (k & 3) * 4);
+  }
+  static __device__ __forceinline__ frag_t load_sw(const char* tile, int row, int ks, int lane, int swz) {
+    const int k = ks * 2 + (lane >> 5);
+    return *reinterpret_cast<const float*>(tile + row * 128 + ((k >> 2) ^ swz) * 16 + (k & 3) * 4);
   }
   static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -77,8 +84,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   // HALO (3x3 s1 p1): the M tile is an 8 x 16 patch of output positions; its 10 x 18 input halo (192 LDS rows with the
   // tail of the last load round) is loaded ONCE per 64-channel slice and the 9 taps read shifted rows of it.
   constexpr int HPW = 16, HPH = BM / HPW, HW2 = HPW + 2, HROWS = (HPH + 2) * HW2, HRND = (HROWS + NT / 8 - 1) / (NT / 8);
-  constexpr int STAGE = HALO ? (BN + HRND * (NT / 8)) * 128 : (BM + BN) * 128;
-  static_assert(!HALO || (NBUF == 1 && BM == 128 && NT == 256), "halo mode: 128-row tiles, single stage");
+  constexpr int HALLOC = (HROWS + 7) / 8 * 8;  // rows written: whole 8-row wave loads up to the last real halo row
+  constexpr int STAGE = HALO ? (BN + HALLOC) * 128 : (BM + BN) * 128;
+  static_assert(!HALO || (NBUF == 1 && (BM == 128 || BM == 256)), "halo mode: 8x16 or 16x16 patches, single stage");
   static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,13 +183,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
       const int hy = hrow / HW2, hx = hrow - hy * HW2;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)sd.in_H && (unsigned)ix < (unsigned)sd.in_W;
-      hsrc[t] = (sd.in_row0 + iy * sd.in_W + ix) * a.in_ld + cl * EPC + goff_h;
+      // bank swizzle keyed on the halo COLUMN: a fragment read covers 16 consecutive columns spread over two
+      // halo rows (8 x 16 patch rows are 18 apart), and 18 is even, so (hx & 1, (hx >> 1) & 7) is conflict-free
+      const int clh = c16 ^ ((hx >> 1) & 7);
+      hsrc[t] = (sd.in_row0 + iy * sd.in_W + ix) * a.in_ld + clh * EPC + goff_h;
       hmask |= (ok ? 1u : 0u) << t;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = wm * WTM + i * 32 + (lane & 31);
-      hb[i] = (m / HPW) * HW2 + (m % HPW);
+      hb[i] = (m / HPW) * HW2 + (m % HPW);  // (m % HPW) == (lane & 15) for every i
     }
   }
   if (a.group_cout > 0) {  // grouped conv: this N tile's group reads its own input-channel window
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
       if (tap == 0) {
 #pragma unroll
         for (int t = 0; t < HRND; ++t) {
+          if (t * RS + wave * 8 >= HALLOC) continue;  // wave-uniform: nothing of the halo in this wave's 8 rows
           const T* src = ((hmask >> t) & 1u) ? in + (hsrc[t] + cc * BK) : zero + cl * EPC;
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dH + t * RS * 128), 16, 0, 0);
         }
@@ -287,7 +299,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
       typename Mma<T>::frag_t fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = Mma<T>::load(tA, HALO ? hb[i] + hoff : wm * WTM + i * 32 + (lane & 31), ks, lane);
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (HALO) fa[i] = Mma<T>::load_sw(tA, hb[i] + (hoff >> 8), ks, lane, (((lane & 15) + (hoff & 255)) >> 1) & 7);
+        else fa[i] = Mma<T>::load(tA, wm * WTM + i * 32 + (lane & 31), ks, lane);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[j] = Mma<T>::load(tB, wn * WTN + j * 32 + (lane & 31), ks, lane);
 #pragma unroll
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 
   if (NBUF == 1) {
     for (int kt = 0; kt < nk; ++kt) {
-      const int hoff = kh * HW2 + kw;  // halo row offset of the tap about to be fetched / computed
+      const int hoff = ((kh * HW2 + kw) << 8) | kw;  // halo row offset (and column shift) of the tap about to be fetched
       issue(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -539,7 +554,7 @@ template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF,
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  const size_t stage = HALO ? (size_t)(BN + 192) * 128 : (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
+  const size_t stage = HALO ? (size_t)(BN + (BM == 256 ? 328 : 184)) * 128 : (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
   size_t lds = stage > epi ? stage : epi;
   if (a.res_lds) lds += (size_t)BM * BN * sizeof(T);
   if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
@@ -628,6 +643,9 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   if (!a.zeros) return -5;
   if (dt == DT_BF16) {
     if (a.halo) {  // 3x3 s1 p1 with patch tiles (sylph_api.hip builds the matching tile table)
+      if (BM == 256 && BN == 128 && !out_f32 && g_nbuf == 1)  // 16 x 16 patches, 8 waves
+        return fast_ok(a, BN) ? launch_cfg<bf16_t, bf16_t, 256, 128, 4, 2, 1, true, true>(a, s)
+                              : launch_cfg<bf16_t, bf16_t, 256, 128, 4, 2, 1, false, true>(a, s);
       if (g_nbuf != 1 || BM != 128 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.stem || a.in2) return -9;
       if (BN == 32) {  // narrow prediction convs (bbox/ctrness, code-generator heads): fp32 or bf16 out
         return out_f32 ? launch_cfg<bf16_t, float, 128, 32, 4, 1, 1, false, true>(a, s)

@@ -335,11 +335,11 @@ static int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geo
 }
 
 // 3x3 s1 p1 halo mode (conv_igemm.hip HALO): M tiles are 8 x 16 patches of one segment, tile.y = (row << 16) | col
-static int make_geom_patch(sylph_ctx* c, const std::vector<SegDesc>& segs, Geom* g) {
+static int make_geom_patch(sylph_ctx* c, const std::vector<SegDesc>& segs, int PH, Geom* g) {
   std::vector<int2> tiles;
   for (size_t s = 0; s < segs.size(); ++s) {
     const int t0 = (int)tiles.size();
-    for (int y = 0; y < segs[s].out_H; y += 8)
+    for (int y = 0; y < segs[s].out_H; y += PH)
       for (int x = 0; x < segs[s].out_W; x += 16) tiles.push_back(make_int2((int)s, (y << 16) | x));
     g->seg_tiles.push_back(make_int2(t0, (int)tiles.size() - t0));
   }
@@ -400,13 +400,16 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   static const int halo_on = getenv("SYLPH_CONV_HALO") ? atoi(getenv("SYLPH_CONV_HALO")) : 1;
   bool halo = halo_on && c->dt == DT_BF16 && BM == 128 && (BN == 32 || (!o.out_f32 && (BN == 128 || BN == 64))) && L.KH == 3 && L.KW == 3 &&
               o.stride == 1 && o.pad == 1 && !o.stem && !o.in2 && L.Cin % 64 == 0;
+  static const int halo_bm = getenv("SYLPH_CONV_HALO_BM") ? atoi(getenv("SYLPH_CONV_HALO_BM")) : 128;
+  if (halo && halo_bm == 256 && BN == 128 && !o.out_f32 && rows >= 256 * 1024) BM = 256;
   if (halo) {  // patches must not waste much of the launch on ragged edges (tiny pyramid levels are cheap anyway)
     long patch_rows = 0;
-    for (auto& sg : segs) patch_rows += (long)((sg.out_H + 7) / 8) * ((sg.out_W + 15) / 16) * 128;
+    const int PH = BM / 16;
+    for (auto& sg : segs) patch_rows += (long)((sg.out_H + PH - 1) / PH) * ((sg.out_W + 15) / 16) * BM;
     if (halo_on != 2 && patch_rows * 10 > rows * 13) halo = false;
   }
   Geom g;
-  if (halo) RET(make_geom_patch(c, segs, &g));
+  if (halo) RET(make_geom_patch(c, segs, BM / 16, &g));
   else RET(make_geom(c, segs, BM, &g));
   ConvArgs a;
   memset(&a, 0, sizeof(a));
