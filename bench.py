@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--code-scale", type=float, default=3.0,
                     help="multiplier on the normalised class codes so the random-weight detector fires (SURVEY 8d)")
+    ap.add_argument("--inflight", type=int, default=2, help="query steps enqueued before the oldest one's counts are read back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket conv launches with HIP events (roofline fields become 0)")
@@ -126,22 +127,33 @@ def main():
     # ---- query steps -----------------------------------------------------------------------------
     queries = dev_images(B, H, Wd, 7 + rank, device)
 
-    def step():
+    # One step = one batch through preprocess -> backbone+FPN -> head -> decode+NMS.  With --inflight 2 (default) the
+    # host enqueues step k+1 before it reads back the detection counts of step k (same stream, same engine: the
+    # device work is unchanged and strictly ordered; only the host-side readback gap is hidden).
+    def launch():
         eng.preprocess(queries)
         eng.backbone()
         eng.head(cls_conv, cls_bias)
-        return eng.decode()
+        return eng.decode_launch()
 
-    for _ in range(args.warmup):
-        dets = step()
+    def run_steps(n):
+        pending, out = [], None
+        for _ in range(n):
+            pending.append(launch())
+            if len(pending) >= args.inflight:
+                out = eng.decode_fetch(pending.pop(0))
+        while pending:
+            out = eng.decode_fetch(pending.pop(0))
+        return out
+
+    dets = run_steps(args.warmup)
     eng.profile_enable(not args.no_kernel_events)
     eng.profile_read()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        dets = step()
+    dets = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -178,7 +190,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: R-50-FPN 5-way 5-shot, 800x1333 synthetic queries",
-                       "batch_per_gpu": B, "ways": N, "shots": S, "image": [H, Wd], "code_scale": args.code_scale,
+                       "batch_per_gpu": B, "steps_in_flight": args.inflight, "ways": N, "shots": S, "image": [H, Wd], "code_scale": args.code_scale,
                        "parallelism": f"dp{world} (queries sharded, codes all-gathered once per episode)",
                        "detections_last_step": ndet},
             "images_per_sec_per_gpu": round(value / world, 2),

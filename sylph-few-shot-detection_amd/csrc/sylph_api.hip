@@ -160,6 +160,7 @@ struct Plan {
   int cand_cap = 0, pool_cap = 0;
   ImageOut* img_out_dev = nullptr;
   ImageOut* img_out_host = nullptr;
+  hipEvent_t img_out_ev = nullptr;  // recorded after the H2D copy of img_out_host (guards its reuse without a stream sync)
   // support
   LevelDesc* lv_dev = nullptr;
   void *roi = nullptr, *cgA = nullptr, *cgB = nullptr;
@@ -1000,6 +1001,7 @@ void sylph_ctx_destroy(sylph_ctx* c) {
   for (auto& kv : c->plans) {
     if (kv.second->img_desc_host) (void)hipHostFree(kv.second->img_desc_host);
     if (kv.second->img_out_host) (void)hipHostFree(kv.second->img_out_host);
+    if (kv.second->img_out_ev) (void)hipEventDestroy(kv.second->img_out_ev);
   }
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
@@ -1395,7 +1397,10 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   if (!P || !P->head_built || !P->logits) return fail("sylph_fcos_head must be called first");
   if (max_out <= 0) return fail("max_out must be positive");
   RET(build_decode(c, P));
-  HIPCHK(hipStreamSynchronize(c->stream));  // img_out_host reuse
+  // img_out_host is rewritten below: wait only for the previous call's H2D copy of it (long finished in steady
+  // state), not for the stream: the host must stay free to launch the next batch on another stream
+  if (P->img_out_ev) HIPCHK(hipEventSynchronize(P->img_out_ev));
+  else HIPCHK(hipEventCreateWithFlags(&P->img_out_ev, hipEventDisableTiming));
   for (int b = 0; b < P->B; ++b) {
     const int H = oh ? oh[b] : P->img_h[b], W = ow ? ow[b] : P->img_w[b];
     // detector_postprocess: python-double ratios cast to the fp32 tensor dtype
@@ -1405,6 +1410,7 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
     P->img_out_host[b].out_h = (float)H;
   }
   HIPCHK(hipMemcpyAsync(P->img_out_dev, P->img_out_host, sizeof(ImageOut) * P->B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(P->img_out_ev, c->stream));
   DecodeCfg d;
   d.num_classes = P->ncls; d.logits_ld = P->logits_ld; d.pre_nms_thresh = c->cfg.pre_nms_thresh;
   d.pre_nms_topk = c->cfg.pre_nms_topk; d.nms_thresh = c->cfg.nms_thresh; d.post_nms_topk = c->cfg.post_nms_topk;

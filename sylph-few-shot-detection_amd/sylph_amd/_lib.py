@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void
 import torch  # noqa: F401  (loads the HIP runtime first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsylph_hip.so")
+LIB_PATH = os.environ.get("SYLPH_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libsylph_hip.so")  # override: A/B kernel builds
 
 SYLPH_F32 = 0
 SYLPH_BF16 = 1

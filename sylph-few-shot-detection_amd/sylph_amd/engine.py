@@ -239,6 +239,11 @@ class Engine:
     def decode(self, out_sizes: Optional[List[Tuple[int, int]]] = None, max_out: Optional[int] = None):
         """-> per image dict of device tensors (pred_boxes, scores, pred_classes, fpn_levels, locations,
         cand_index).  One device->host copy of the per-image counts (the only sync of a query step)."""
+        return self.decode_fetch(self.decode_launch(out_sizes, max_out))
+
+    def decode_launch(self, out_sizes: Optional[List[Tuple[int, int]]] = None, max_out: Optional[int] = None):
+        """Enqueue decode + NMS on the current stream and return a handle WITHOUT synchronising: the caller can
+        launch the next batch (another Engine on another stream) before `decode_fetch` reads the counts back."""
         self._stream()
         B = self._batch[0]
         K = int(self.sc.post_nms_topk)
@@ -257,13 +262,26 @@ class Engine:
         check(self.L.sylph_decode_nms(self._ctx, oh, ow, max_out, _ptr(boxes), _ptr(scores), _ptr(classes),
                                       _ptr(levels), _ptr(locs), _ptr(cand), _ptr(counts),
                                       c_void_p(counts.data_ptr() + 4 * B)), "decode_nms")
-        cnt = counts.cpu().tolist()
+        host_counts = torch.empty(B + 1, dtype=torch.int32, pin_memory=True)
+        host_counts.copy_(counts, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return (B, boxes, scores, classes, levels, locs, cand, host_counts, done, torch.cuda.current_stream(dev))
+
+    def decode_fetch(self, handle):
+        B, boxes, scores, classes, levels, locs, cand, host_counts, done, stream = handle
+        done.synchronize()
+        cnt = host_counts.tolist()
         status = cnt[B]
         if status & 1:
             raise RuntimeError("sylph decode: per-level candidate capacity exceeded (raise cand_cap)")
         if status & 2:
             raise RuntimeError("sylph decode: more tied detections than max_out")
-        classes, levels, cand = classes.long(), levels.long(), cand.long()  # 3 launches, then views only
+        with torch.cuda.stream(stream):
+            classes, levels, cand = classes.long(), levels.long(), cand.long()  # 3 launches, then views only
+        cur = torch.cuda.current_stream(self.device)
+        if cur != stream:
+            cur.wait_stream(stream)
         res = []
         for i in range(B):
             n = cnt[i]
