@@ -607,7 +607,8 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN, bool 
     return;
   }
   int bn = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
-  if (ntaps == 1 && bn == 128 && cout % 64 == 0) bn = 64;
+  // (pointwise convs used to prefer 128x64 for occupancy; since the per-tile instruction diet 128x128 is equal or
+  // better on every bottleneck 1x1: less LDS-DMA traffic per flop)
   if (const char* f = getenv("SYLPH_CONV_FORCE_BN")) {  // tuning knob
     const int v = atoi(f);
     if ((v == 64 || v == 128 || v == 256) && cout % v == 0) bn = v;
