@@ -91,6 +91,14 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
   *reinterpret_cast<bf16x8*>(p) = o;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for every global
+// store (and prefetch load) still in flight: ~1-2 us per barrier in an epilogue that has just issued its stores.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- launcher prototypes (one per translation unit) -----------------------------------------
 // conv_igemm.hip
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);

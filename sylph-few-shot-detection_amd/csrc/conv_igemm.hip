@@ -376,7 +376,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     OutT* __restrict__ outn = out + (size_t)sd.out_row0 * a.out_ld + n0;
 #pragma unroll
     for (int p = 0; p < WGM; ++p) {
-      if (p > 0) __syncthreads();
+      if (p > 0) lds_barrier();
       if (wm == p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
               *reinterpret_cast<float4*>(sC + (i * 32 + (lane & 31)) * SCP + wn * WTN + j * 32 + 8 * g + 4 * (lane >> 5)) =
                   make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
       }
-      __syncthreads();
+      lds_barrier();
       if (p == 0 && BN <= 64) {
         const float* ssl = reinterpret_cast<const float*>(smem + ss_off);
 #pragma unroll
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   // one group; per-lane shifted sums -> (count, mean, M2), combined (Chan) in a fixed order below.
   float gn_n = 0.f, gn_pv = 0.f, gn_s1 = 0.f, gn_s2 = 0.f;
   for (int p = 0; p < WGM; ++p) {
-    if (p > 0) __syncthreads();
+    if (p > 0) lds_barrier();
     if (wm == p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
                 make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
           }
     }
-    __syncthreads();
+    lds_barrier();
     if (p == 0 && BN <= 64 && a.ss_padded) {
       const float* ssl = reinterpret_cast<const float*>(smem + ss_off);
 #pragma unroll
@@ -525,13 +525,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     }
   }
   if (a.gn_partial) {
-    __syncthreads();
+    lds_barrier();
     float* red = sC;  // [RPP][TPR][3]
     const float inv_n = gn_n > 0.f ? 1.f / gn_n : 0.f;
     red[(rr * TPR + c8) * 3 + 0] = gn_n;
     red[(rr * TPR + c8) * 3 + 1] = gn_pv + gn_s1 * inv_n;          // lane mean
     red[(rr * TPR + c8) * 3 + 2] = gn_s2 - gn_s1 * gn_s1 * inv_n;  // lane M2
-    __syncthreads();
+    lds_barrier();
     if (rr == 0 && active) {
       float N = 0.f, M = 0.f, Q = 0.f;
       for (int r = 0; r < RPP; ++r) {

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(PNT, 1) void conv_pipe_kernel(const ConvArgs a) {
   float gn_n = 0.f, gn_pv = 0.f, gn_s1 = 0.f, gn_s2 = 0.f;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    if (p > 0) __syncthreads();
+    if (p > 0) lds_barrier();
     if (wm == (p >> 1)) {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(PNT, 1) void conv_pipe_kernel(const ConvArgs a) {
                 make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
           }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int rl = rr + 16 * it;
@@ -289,13 +289,13 @@ __global__ __launch_bounds__(PNT, 1) void conv_pipe_kernel(const ConvArgs a) {
     }
   }
   if (a.gn_partial) {
-    __syncthreads();
+    lds_barrier();
     float* red = sC;  // [16][32][3]
     const float inv_n = gn_n > 0.f ? 1.f / gn_n : 0.f;
     red[(rr * 32 + c8) * 3 + 0] = gn_n;
     red[(rr * 32 + c8) * 3 + 1] = gn_pv + gn_s1 * inv_n;       // lane mean
     red[(rr * 32 + c8) * 3 + 2] = gn_s2 - gn_s1 * gn_s1 * inv_n;  // lane M2
-    __syncthreads();
+    lds_barrier();
     if (rr == 0) {
       float N = 0.f, M = 0.f, Q = 0.f;
       for (int r = 0; r < 16; ++r) {

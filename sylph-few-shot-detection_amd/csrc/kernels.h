@@ -65,6 +65,9 @@ int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int
 int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s);
+// stem_conv.hip
+int launch_stem_conv(const void* x, const void* wp, const float* scale, const float* shift, void* out, int B, int H, int W, int H2,
+                     int W2, hipStream_t s);
 int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg* segs_dev, int nseg, int max_rows,
                              const float* partial, float2* stats_ws, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s);

@@ -1,0 +1,179 @@
+// ResNet stem: 7x7 stride-2 pad-3 conv (3 -> 64) + FrozenBN + ReLU, bf16, as a dedicated MFMA kernel.
+//
+// Reference op: detectron2 BasicStem.conv1 (+ norm + relu) as used by build_resnet_fpn_backbone
+// (sylph/modeling/backbone/fpn.py:21-45).  The generic implicit-GEMM kernel runs this layer LDS-DMA bound: with
+// only 3 input channels every 128-byte K-slice is a fresh gather, 96 KB of loads per 128x64 tile.  Here the input
+// patch of a tile (21 x 38 pixels x 4 channels = 6.4 KB) is staged once in LDS and the im2col happens in the
+// fragment reads; the weights (64 x 224 bf16) live in REGISTERS for the whole persistent block:
+//
+//   * tile = 8 x 16 output positions x 64 channels, 4 waves, wave w = patch rows 2w, 2w+1 (32 positions);
+//   * K = 7 kernel rows x (8 pixels x 4 channels) = 224 = 14 MFMA k-steps (pixel 7 and channel 3 carry zero
+//     weights); k-step (kh, h): lane (position, lh) reads the 2 pixels kw = 4h + 2lh, +1 of input row 2py + kh:
+//     one aligned ds_read_b128 at ((2py + kh) * 48 + 2px + 4h + 2lh) * 8 bytes.  The 48-pixel patch pitch makes two
+//     consecutive patch rows 768 B = 0 mod 256 apart, so every ds_read_b128 lane group covers all 64 banks once;
+//   * D^T MFMA (weights as the A operand): a lane ends up with 4 consecutive channels of one position; the
+//     epilogue goes through an fp32 LDS tile like conv_igemm.hip (scale/shift, ReLU, 16-byte stores);
+//   * persistent blocks (grid-stride over tiles); the patches of the next two tiles are in flight in registers.
+#include "common.h"
+
+namespace sylph {
+
+namespace {
+constexpr int PP = 48;                 // patch pitch in pixels
+constexpr int PROWS = 21, PCOLS = 38;  // patch extent actually read
+constexpr int PATCH_BYTES = 8192;      // 21 * 48 * 8 = 8064, rounded
+constexpr int SCP = 68;                // fp32 pitch of the epilogue tile (64 + 4)
+constexpr int NLOAD = (PROWS * PCOLS + 255) / 256;  // 8-byte pixel loads per lane per tile (4)
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           bf16_t* __restrict__ out, int H, int W, int H2, int W2,
+                                                           int tiles_y, int tiles_x, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  float* sC = reinterpret_cast<float*>(smem + PATCH_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+
+  // weights -> registers: k-step ks = (kh, h), fragment j = channels 32j .. 32j+31
+  bf16x8 wb[14][2];
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wb[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (j * 32 + l31) * 224 + ks * 16 + lh * 8);
+
+  const int m = wave * 32 + l31, py = m >> 4, px = m & 15;
+  const int aoff = ((2 * py) * PP + 2 * px + 2 * lh) * 8;
+
+  const int c8 = tid & 7, rr = tid >> 3;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 s4 = reinterpret_cast<const float4*>(scale + c8 * 8)[h], b4 = reinterpret_cast<const float4*>(shift + c8 * 8)[h];
+    sc[4 * h] = s4.x; sc[4 * h + 1] = s4.y; sc[4 * h + 2] = s4.z; sc[4 * h + 3] = s4.w;
+    sh[4 * h] = b4.x; sh[4 * h + 1] = b4.y; sh[4 * h + 2] = b4.z; sh[4 * h + 3] = b4.w;
+  }
+
+  // Loads are UNCONDITIONAL (clamped address, value zeroed afterwards) and fetch() runs every iteration (clamped
+  // tile): with a static number of loads per tile the compiler can retire a patch with a counted vmcnt instead of
+  // vmcnt(0), which would also wait for the previous tile's output stores and for the other patch in flight.
+  auto fetch = [&](int tile_in, uint2 (&v)[NLOAD], uint32_t& okmask) {
+    const int tile = tile_in < ntiles ? tile_in : ntiles - 1;
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int iy0 = ty * 16 - 3, ix0 = tx * 32 - 3;
+    okmask = 0;
+#pragma unroll
+    for (int r = 0; r < NLOAD; ++r) {
+      const int idx = tid + 256 * r;
+      const int pr = idx / PCOLS, pc = idx - pr * PCOLS;
+      const int iy = iy0 + pr, ix = ix0 + pc;
+      const bool ok = idx < PROWS * PCOLS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+      // issued through inline asm so that the compiler does not schedule a vmcnt(0) of its own before park():
+      // the wait is the counted one in do_tile() (loads retire in order, so <= NLOAD outstanding ops means this
+      // patch has landed while the other patch may still be in flight)
+      const bf16_t* src = x + (((size_t)b * H + cy) * W + cx) * 4;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v[r]) : "v"(src) : "memory");
+      okmask |= (ok ? 1u : 0u) << r;
+    }
+  };
+  auto park = [&](const uint2 (&v)[NLOAD], uint32_t okmask) {
+#pragma unroll
+    for (int r = 0; r < NLOAD; ++r) {
+      const int idx = tid + 256 * r;
+      const int pr = idx / PCOLS, pc = idx - pr * PCOLS;
+      const uint2 t = ((okmask >> r) & 1u) ? v[r] : make_uint2(0u, 0u);
+      if (idx < PROWS * PCOLS) *reinterpret_cast<uint2*>(patch + (pr * PP + pc) * 8) = t;
+    }
+  };
+
+  // the weight / scale / shift loads retire here, once: inside the loop only patch loads and output stores are in flight
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(wb[ks][j]));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { asm volatile("" : "+v"(sc[e])); asm volatile("" : "+v"(sh[e])); }
+
+  // One tile: park its patch (fetched two tiles ago), immediately re-use the same registers to fetch the patch of
+  // the tile two steps ahead, MFMAs, epilogue.  Two register sets alternate, so no load is ever waited for (or
+  // moved) before its own park: the ~2 us HBM round trip is longer than one tile's work.
+  const int g = gridDim.x;
+  auto do_tile = [&](int tile, uint2 (&q)[NLOAD], uint32_t& qm) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(NLOAD == 4, "the vmcnt immediate above is NLOAD");
+    park(q, qm);
+    lds_barrier();
+    fetch(tile + 2 * g, q, qm);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(patch + aoff + (kh * PP + 4 * h) * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kh * 2 + h][j], fa, acc[j], 0, 0, 0);
+      }
+
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int oy0 = ty * 8, ox0 = tx * 16;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {  // 64 positions per pass: waves 2p, 2p+1
+      if (p > 0) lds_barrier();
+      if ((wave >> 1) == p) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            *reinterpret_cast<float4*>(sC + ((wave & 1) * 32 + l31) * SCP + j * 32 + 8 * q4 + 4 * lh) =
+                make_float4(acc[j][4 * q4], acc[j][4 * q4 + 1], acc[j][4 * q4 + 2], acc[j][4 * q4 + 3]);
+      }
+      lds_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int rl = rr + 32 * it, mm = p * 64 + rl;
+        const int oy = oy0 + (mm >> 4), ox = ox0 + (mm & 15);
+        if (oy < H2 && ox < W2) {
+          const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = v[e] * sc[e] + sh[e]; v[e] = v[e] > 0.f ? v[e] : 0.f; }
+          store8<bf16_t>(out + (((size_t)b * H2 + oy) * W2 + ox) * 64 + c8 * 8, v);
+        }
+      }
+    }
+    lds_barrier();  // patch and sC are rewritten by the next tile
+  };
+
+  uint2 qa[NLOAD], qb[NLOAD];
+  uint32_t ma, mb;
+  int tile = blockIdx.x;
+  fetch(tile, qa, ma);
+  fetch(tile + g, qb, mb);
+  while (tile < ntiles) {
+    do_tile(tile, qa, ma);
+    tile += g;
+    if (tile >= ntiles) break;
+    do_tile(tile, qb, mb);
+    tile += g;
+  }
+}
+
+// wp: [64][7][8][4] bf16 (kernel column 7 and channel 3 zero); x: [B][H][W][4]; out: [B][H2][W2][64]
+int launch_stem_conv(const void* x, const void* wp, const float* scale, const float* shift, void* out, int B, int H, int W, int H2,
+                     int W2, hipStream_t s) {
+  const int tiles_y = (H2 + 7) / 8, tiles_x = (W2 + 15) / 16, ntiles = B * tiles_y * tiles_x;
+  const int grid = ntiles < 512 ? ntiles : 512;  // 2 persistent blocks per CU
+  const size_t lds = PATCH_BYTES + (size_t)64 * SCP * 4;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)wp, scale, shift, (bf16_t*)out,
+                     H, W, H2, W2, tiles_y, tiles_x, ntiles);
+  return (int)hipGetLastError();
+}
+
+}  // namespace sylph

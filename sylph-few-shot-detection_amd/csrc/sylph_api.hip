@@ -80,6 +80,7 @@ struct sylph_ctx {
   std::map<std::string, HostTensor> host_w;
   // packed model
   ConvLayer stem;  // 7x7 s2 stem packed for the implicit-GEMM stem loader
+  void* stem_wp = nullptr;  // bf16 [64][7][8][4] for the dedicated stem kernel (stem_conv.hip)
   struct Block { ConvLayer c1, c2, c3, sc, c3sc; bool has_sc = false, fused_sc = false; };
   std::vector<std::vector<Block>> stages;  // res2..res5
   ConvLayer fpn_lat[3], fpn_out[3], p6, p7;  // index 0..2 = stage 3..5
@@ -372,6 +373,24 @@ static int timed_conv(sylph_ctx* c, DType dt, bool of32, const ConvArgs& a, int 
   return rc;
 }
 
+// any other launch that should count as conv work in the profile (dedicated stem kernel)
+static int timed_op(sylph_ctx* c, double flops, hipStream_t s, const std::function<int(hipStream_t)>& fn) {
+  if (!c->prof) return fn(s);
+  sylph_ctx::ProfRec r;
+  if (!c->prof_free.empty()) {
+    r.a = c->prof_free.back().first; r.b = c->prof_free.back().second;
+    c->prof_free.pop_back();
+  } else {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -100;
+  }
+  r.flops = flops;
+  (void)hipEventRecord(r.a, s);
+  const int rc = fn(s);
+  (void)hipEventRecord(r.b, s);
+  c->prof_recs.push_back(r);
+  return rc;
+}
+
 struct ConvOpts {
   int stride = 1, pad = 0;
   int relu_nch = 0, mul_nch = 0;
@@ -523,7 +542,17 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
     void *so = P->stem_out, *po = P->pool_out;
     ConvOpts os; os.stem = 1; os.relu_nch = 1 << 30;
     os.flops = 2.0 * (double)B * H2 * W2 * 64.0 * 147.0;
-    RET(add_conv(c, ops, c->stem, P->x0, 4, so, 64, image_segs(B, H, W, H2, W2), os));
+    static const int stem_fast = getenv("SYLPH_STEM_KERNEL") ? atoi(getenv("SYLPH_STEM_KERNEL")) : 1;
+    if (dt == DT_BF16 && c->stem_wp && stem_fast) {
+      const void *x0 = P->x0, *wp = c->stem_wp;
+      const float *scl = c->stem.scale, *shf = c->stem.shift;
+      const double fl = os.flops;
+      ops.push_back([=](hipStream_t s) {
+        return timed_op(c, fl, s, [=](hipStream_t st) { return launch_stem_conv(x0, wp, scl, shf, so, B, H, W, H2, W2, st); });
+      });
+    } else {
+      RET(add_conv(c, ops, c->stem, P->x0, 4, so, 64, image_segs(B, H, W, H2, W2), os));
+    }
     ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
   }
   const void* X = P->pool_out;
@@ -1064,6 +1093,16 @@ int sylph_finalize_weights(sylph_ctx* c) {
       }
       RET(upload_vec(c, &c->stem.scale, sc, c->stem.Cout_pad));
       RET(upload_vec(c, &c->stem.shift, sh, c->stem.Cout_pad));
+      if (c->dt == DT_BF16) {  // dedicated stem kernel: [n][kh][8 px][4 ch], kernel column 7 / channel 3 zero
+        std::vector<bf16_t> wp((size_t)64 * 224);
+        for (int n = 0; n < 64; ++n)
+          for (int kh = 0; kh < 7; ++kh)
+            for (int px = 0; px < 8; ++px)
+              for (int ch = 0; ch < 4; ++ch)
+                wp[(size_t)n * 224 + kh * 32 + px * 4 + ch] =
+                    (bf16_t)((px < 7 && ch < 3) ? w->data[((n * 3 + ch) * 7 + kh) * 7 + px] : 0.f);
+        RET(upload(c, &c->stem_wp, wp.data(), wp.size() * sizeof(bf16_t)));
+      }
     }
     const int nb50[4] = {3, 4, 6, 3}, nb101[4] = {3, 4, 23, 3}, nb152[4] = {3, 8, 36, 3};
     const int* nb = c->cfg.resnet_depth == 50 ? nb50 : (c->cfg.resnet_depth == 101 ? nb101 : nb152);
