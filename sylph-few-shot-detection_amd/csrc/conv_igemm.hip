@@ -359,6 +359,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     }
   }
   if constexpr (FAST) {
+    static_assert(sizeof(T) == 2, "FAST epilogue: bf16 activations");
     // Launch-time guarantees (launch_conv): Cout % BN == 0, 16-byte aligned rows, padded scale/shift, no
     // per-segment Scale, no GroupNorm partials, ReLU on all channels or none.  The row loop is then
     // branch-free apart from the residual mode: these short-K tiles are instruction-issue bound.
@@ -393,8 +394,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc[e] = ssl[c8 * 8 + e]; sh[e] = ssl[BN + c8 * 8 + e]; }
       }
+      // Two sweeps over this pass's rows: first every residual load is issued, then the math and the stores.
+      // (vmcnt retires in order, so a residual load issued after a store would also wait for that store.)
+      constexpr int ITERS = (WTM + RPP - 1) / RPP;
+      int posv[ITERS];
+      bool pvv[ITERS];
+      uint4 rraw[ITERS];
 #pragma unroll
-      for (int it = 0; it < (WTM + RPP - 1) / RPP; ++it) {
+      for (int it = 0; it < ITERS; ++it) {
         const int rl = rr + it * RPP;
         int pos = tile.y + p * WTM + rl;
         bool pv = pos < seg_rows;
@@ -403,29 +410,40 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
           pos = oy * sd.out_W + ox;
           pv = oy < sd.out_H && ox < sd.out_W;
         }
-        if ((WTM % RPP == 0 || rl < WTM) && pv) {
+        posv[it] = pos;
+        pvv[it] = (WTM % RPP == 0 || rl < WTM) && pv;
+        rraw[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (a.res_mode != 0 && pvv[it]) {
+          int rp = pos;
+          if (a.res_mode == 2) {
+            const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
+            rp = (oy >> 1) * sd.res_W + (ox >> 1);
+          }
+          rraw[it] = *reinterpret_cast<const uint4*>(resn + (size_t)(sd.res_row0 + rp) * a.res_ld);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int rl = rr + it * RPP;
+        if (pvv[it]) {
           float v[8];
           const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
           const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
           v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-          if (a.res_mode != 0) {
-            int rp = pos;
-            if (a.res_mode == 2) {
-              const int oy = pos / sd.out_W, ox = pos - oy * sd.out_W;
-              rp = (oy >> 1) * sd.res_W + (ox >> 1);
-            }
-            float rv[8];
-            load8<T>(resn + (size_t)(sd.res_row0 + rp) * a.res_ld, rv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          if (a.res_mode != 0) {  // FAST is bf16 only: 8 residual channels = one 16-byte load
+            const uint4 r4 = rraw[it];
+            v[0] += __uint_as_float(r4.x << 16); v[1] += __uint_as_float(r4.x & 0xffff0000u);
+            v[2] += __uint_as_float(r4.y << 16); v[3] += __uint_as_float(r4.y & 0xffff0000u);
+            v[4] += __uint_as_float(r4.z << 16); v[5] += __uint_as_float(r4.z & 0xffff0000u);
+            v[6] += __uint_as_float(r4.w << 16); v[7] += __uint_as_float(r4.w & 0xffff0000u);
           }
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          store8<OutT>(outn + (size_t)pos * a.out_ld, v);
+          store8<OutT>(outn + (size_t)posv[it] * a.out_ld, v);
         }
       }
     }
