@@ -72,6 +72,33 @@ template <> struct Mma<float> {
   }
 };
 
+// Per-tile GroupNorm partial: every lane holds shifted sums over its rows of one 8-channel group; the RPP lanes of a
+// group are merged (Chan) in a fixed order by lane row 0 and written as (n, mean, M2).
+template <int RPP, int TPR>
+__device__ __forceinline__ void gn_tile_reduce(float* red, int rr, int c8, float gn_n, float gn_pv, float gn_s1, float gn_s2,
+                                               float* gp, bool active) {
+  lds_barrier();
+  const float inv_n = gn_n > 0.f ? 1.f / gn_n : 0.f;
+  red[(rr * TPR + c8) * 3 + 0] = gn_n;
+  red[(rr * TPR + c8) * 3 + 1] = gn_pv + gn_s1 * inv_n;          // lane mean
+  red[(rr * TPR + c8) * 3 + 2] = gn_s2 - gn_s1 * gn_s1 * inv_n;  // lane M2
+  lds_barrier();
+  if (rr == 0 && active) {
+    float N = 0.f, M = 0.f, Q = 0.f;
+    for (int r = 0; r < RPP; ++r) {
+      const float nb = red[(r * TPR + c8) * 3 + 0];
+      if (nb > 0.f) {
+        const float mb = red[(r * TPR + c8) * 3 + 1], qb = red[(r * TPR + c8) * 3 + 2];
+        const float nn = N + nb, delta = mb - M;
+        M += delta * (nb / nn);
+        Q += qb + delta * delta * (N * nb / nn);
+        N = nn;
+      }
+    }
+    gp[0] = N; gp[1] = M; gp[2] = Q;
+  }
+}
+
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : (BM * BN >= 256 * 128 ? 2 : (BM * BN == 128 * 128 ? 4 : 1))))) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -373,6 +400,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
       }
     }
     const bool relu = a.relu_nch > 0;
+    float gn_n = 0.f, gn_pv = 0.f, gn_s1 = 0.f, gn_s2 = 0.f;  // fused GroupNorm statistics (see the generic path)
     const T* __restrict__ resn = res + n0;
     OutT* __restrict__ outn = out + (size_t)sd.out_row0 * a.out_ld + n0;
 #pragma unroll
@@ -443,10 +471,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
+          if (a.gn_partial) {
+            if (gn_n == 0.f) gn_pv = 0.125f * (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - gn_pv; gn_s1 += d; gn_s2 = fmaf(d, d, gn_s2); }
+            gn_n += 8.f;
+          }
           store8<OutT>(outn + (size_t)posv[it] * a.out_ld, v);
         }
       }
     }
+    if (a.gn_partial) gn_tile_reduce<RPP, TPR>(sC, rr, c8, gn_n, gn_pv, gn_s1, gn_s2, a.gn_partial + ((size_t)mt * (a.Cout >> 3) + (n0 >> 3)) * 3, true);
     return;
   }
   // GroupNorm(32 x 8 channels) statistics of the fp32 outputs, fused: a lane's 8 channels are exactly
@@ -542,30 +577,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
       }
     }
   }
-  if (a.gn_partial) {
-    lds_barrier();
-    float* red = sC;  // [RPP][TPR][3]
-    const float inv_n = gn_n > 0.f ? 1.f / gn_n : 0.f;
-    red[(rr * TPR + c8) * 3 + 0] = gn_n;
-    red[(rr * TPR + c8) * 3 + 1] = gn_pv + gn_s1 * inv_n;          // lane mean
-    red[(rr * TPR + c8) * 3 + 2] = gn_s2 - gn_s1 * gn_s1 * inv_n;  // lane M2
-    lds_barrier();
-    if (rr == 0 && active) {
-      float N = 0.f, M = 0.f, Q = 0.f;
-      for (int r = 0; r < RPP; ++r) {
-        const float nb = red[(r * TPR + c8) * 3 + 0];
-        if (nb > 0.f) {
-          const float mb = red[(r * TPR + c8) * 3 + 1], qb = red[(r * TPR + c8) * 3 + 2];
-          const float nn = N + nb, delta = mb - M;
-          M += delta * (nb / nn);
-          Q += qb + delta * delta * (N * nb / nn);
-          N = nn;
-        }
-      }
-      float* gp = a.gn_partial + ((size_t)mt * (a.Cout >> 3) + (n0 >> 3)) * 3;
-      gp[0] = N; gp[1] = M; gp[2] = Q;
-    }
-  }
+  if (a.gn_partial)
+    gn_tile_reduce<RPP, TPR>(sC, rr, c8, gn_n, gn_pv, gn_s1, gn_s2, a.gn_partial + ((size_t)mt * (a.Cout >> 3) + (n0 >> 3)) * 3, active);
 }
 
 template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO = false>
@@ -601,7 +614,7 @@ static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
 static bool fast_ok(const ConvArgs& a, int BN) {
   static const int on = getenv("SYLPH_CONV_FAST") ? atoi(getenv("SYLPH_CONV_FAST")) : 1;
   return on && a.ss_padded_host && (BN > 64 || a.ss_padded) && a.Cout % BN == 0 && (a.out_ld & 7) == 0 && (a.res_mode == 0 || (a.res_ld & 7) == 0) &&
-         !a.gn_partial && a.mul_nch == 0 && (a.relu_nch == 0 || a.relu_nch >= a.Cout);
+         a.mul_nch == 0 && (a.relu_nch == 0 || a.relu_nch >= a.Cout);
 }
 
 template <typename T, typename OutT>
