@@ -1,4 +1,7 @@
-"""conv_pipe_kernel (256x256 deep-pipelined conv) parity.  The kernel is picked automatically only for launches
+"""Parity of the conv kernel variants that the small golden shapes do not select by themselves: the halo-tile
+mode of conv_igemm (picked only when 8x16 patches waste < 30 % of a launch) and conv_pipe_kernel.
+
+conv_pipe_kernel (256x256 deep-pipelined conv) parity.  The kernel is picked automatically only for launches
 with >= 512 tiles, so: (1) a conv large enough to select it is compared with torch, and (2) the head / episode
 parity tests are re-run in a subprocess with SYLPH_CONV_PIPE=2, which forces it for every eligible layer (the
 paired FCOS towers with their fused GroupNorm statistics, FPN output convs) at the small golden sizes."""
@@ -34,5 +37,15 @@ def test_head_and_episode_parity_with_pipe_kernel_forced():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_parity.py"), "-m", "gpu", "-q", "-x",
                         "-k", "head or episode or backbone or codegen or full"], env=env, cwd=ROOT, capture_output=True, text=True,
                        timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_parity_suite_with_halo_mode_forced():
+    """SYLPH_CONV_HALO=2 selects the halo-tile mode for every eligible 3x3 stride-1 conv whatever the patch waste:
+    conv2d vs torch, head / decode / codegen goldens, backbone and episode vs the oracle all run through it."""
+    env = dict(os.environ, SYLPH_CONV_HALO="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_parity.py"), "-m", "gpu", "-q", "-x"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
