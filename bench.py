@@ -175,7 +175,7 @@ def main():
         alg_flops = GFLOP_PER_IMAGE_MFMA_CONV * 1e9 * images_timed  # all conv launches of the region, this rank
         achieved = alg_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         roofline = {
-            "kernel": "conv_igemm_kernel + conv_pipe_kernel (implicit-GEMM MFMA convs, all launches of the timed region)",
+            "kernel": "conv_igemm_kernel (+ stem_conv_kernel): implicit-GEMM MFMA convs, all 63 launches per step of the timed region",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
             "traffic": pmc_traffic_per_launch(B, launches // max(args.steps, 1)),
@@ -209,7 +209,7 @@ def pmc_traffic_per_launch(batch, launches_per_step):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (separate runs of this same
     command: FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; tools/rocpd_pmc.py).
     Scaled from the profiled batch to this run's batch (traffic is per image); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r1_d_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_traffic.json")
     if not os.path.exists(path) or launches_per_step <= 0:
         return None
     with open(path) as f:

@@ -8,5 +8,5 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $CMD
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o w -- $CMD > $OUT/write.log 2>&1 || echo "write pass failed"
 python tools/rocpd_summary.py $OUT/trace/t_results.db $OUT/kernel_summary.md > /dev/null
 python tools/rocpd_timeline.py $OUT/trace/t_results.db > $OUT/timeline.txt
-python tools/rocpd_pmc.py $OUT/fetch/f_results.db $OUT/write/w_results.db 32 $OUT/pmc_hbm_traffic.json | tail -12
+python tools/rocpd_pmc.py $OUT/fetch/f_results.db $OUT/write/w_results.db 64 $OUT/pmc_hbm_traffic.json | tail -12
 head -30 $OUT/kernel_summary.md
