@@ -54,7 +54,7 @@ typedef struct sylph_config {
   int cg_conv_l2_norm;     /* CODE_GENERATOR.CONV_L2_NORM */
   int cg_use_weight_scale; /* CODE_GENERATOR.USE_WEIGHT_SCALE */
   float prior_prob;        /* MODEL.FCOS.PRIOR_PROB */
-  int cand_cap;            /* per (image, level) candidate capacity of the decode scan (0 = default) */
+  int cand_cap;            /* per (image, level) candidate capacity of the decode scan (0 = default: 1/8 of the largest level's location x class scores, at least 65536) */
   /* ROIEncoder variant (sylph/runner/default_configs.py:149-167; LVIS ROI-Encoder yaml) */
   int cg_type;             /* CODE_GENERATOR.NAME: 0 "CodeGenerator", 1 "ROIEncoder" */
   int tok_num_conv;        /* TOKENIZER.NUM_CONV (conv3x3 + GN + ReLU, CONV_DIM 256, NORM "GN") */

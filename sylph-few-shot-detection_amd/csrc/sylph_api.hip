@@ -771,6 +771,18 @@ static int build_head(sylph_ctx* c, Plan* P) {
   return 0;
 }
 
+// Per-(image, level) capacity of the decode candidate buffers.  The reference has no cap (boolean-mask indexing,
+// fcos_outputs.py:960-990); here the scan compacts into a fixed buffer and overflow is reported, so the default
+// leaves room for 1/8 of all (location, class) scores of the largest level passing the threshold: 65 536 for 5-way,
+// 1.8 M for LVIS 866-way (HBM is plentiful: 8 bytes per slot).
+static int want_cand_cap(const sylph_ctx* c, const Plan* P) {
+  if (c->cfg.cand_cap > 0) return c->cfg.cand_cap;
+  long w = (long)P->hl[0] * P->wl[0] * (long)(P->ncls > 0 ? P->ncls : 1) / 8;
+  if (w < 65536) w = 65536;
+  if (w > (1L << 22)) w = 1L << 22;
+  return (int)w;
+}
+
 static int build_decode(sylph_ctx* c, Plan* P) {
   if (P->decode_built) return 0;
   const int L = c->cfg.nlevels, B = P->B, nseg = B * L;
@@ -790,7 +802,7 @@ static int build_decode(sylph_ctx* c, Plan* P) {
   while (pool < L * c->cfg.pre_nms_topk) pool <<= 1;
   if (pool > 8192) return fail("levels * PRE_NMS_TOPK exceeds the 8192-entry on-chip sort capacity");
   P->pool_cap = pool;
-  P->cand_cap = c->cfg.cand_cap > 0 ? c->cfg.cand_cap : 65536;
+  P->cand_cap = want_cand_cap(c, P);
   DecodeBuffers& d = P->dbuf;
   RET(c->dalloc((void**)&d.cand_key, (size_t)nseg * P->cand_cap * 4));
   RET(c->dalloc((void**)&d.cand_idx, (size_t)nseg * P->cand_cap * 4));
@@ -1436,6 +1448,12 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   if (!P || !P->head_built || !P->logits) return fail("sylph_fcos_head must be called first");
   if (max_out <= 0) return fail("max_out must be positive");
   RET(build_decode(c, P));
+  if (want_cand_cap(c, P) > P->cand_cap) {  // more classes than when the plan was built: grow the candidate buffers
+    const int nseg = P->B * c->cfg.nlevels;
+    P->cand_cap = want_cand_cap(c, P);
+    RET(c->dalloc((void**)&P->dbuf.cand_key, (size_t)nseg * P->cand_cap * 4));
+    RET(c->dalloc((void**)&P->dbuf.cand_idx, (size_t)nseg * P->cand_cap * 4));
+  }
   // img_out_host is rewritten below: wait only for the previous call's H2D copy of it (long finished in steady
   // state), not for the stream: the host must stay free to launch the next batch on another stream
   if (P->img_out_ev) HIPCHK(hipEventSynchronize(P->img_out_ev));

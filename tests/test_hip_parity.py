@@ -422,3 +422,45 @@ def test_c3_shape_runs_bf16(full_sd):
     dets = eng.decode()
     assert len(dets) == 16 and all(d["scores"].numel() > 0 for d in dets)
     assert all(int(d["pred_classes"].max()) < 20 for d in dets)
+
+
+def test_c4_shape_runs_bf16_full_size():
+    """BASELINE config C4 at full query size: R-101, 866 classes (LVIS), 300 detections, batch 2 of 800x1333.
+    Exercises the production kernel selection (halo tiles, stem kernel, radix top-k over 866-wide score rows)."""
+    from oracle import weights as W
+    cfg = _cfg(**{"MODEL.RESNETS.DEPTH": 101, "MODEL.FCOS.POST_NMS_TOPK_TEST": 300})
+    eng = _engine("bf16", cfg)
+    eng.load_state_dict(W.synthetic_state_dict(0, depth=101))
+    q = W.synthetic_images(2, 800, 1333, seed=21)
+    codes = W.synthetic_codes(866, seed=22, scale=1.5)  # ~ a few % of the 19.4 M scores per image pass the 0.05 threshold
+    eng.preprocess(q)
+    eng.backbone()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    dets = eng.decode()
+    assert len(dets) == 2
+    for d in dets:
+        n = d["scores"].numel()
+        assert 0 < n and int(d["pred_classes"].max()) < 866
+        s = d["scores"].float().cpu()
+        assert torch.all(s[:-1] >= s[1:]) or n == 1, "NMS output is sorted by score"
+        b = d["pred_boxes"].float().cpu()
+        assert torch.all(b[:, 2] >= b[:, 0]) and torch.all(b[:, 3] >= b[:, 1])
+        assert float(b[:, 2].max()) <= 1333.0 + 1e-3 and float(b[:, 3].max()) <= 800.0 + 1e-3
+
+
+def test_c5_query_shape_runs_bf16():
+    """BASELINE config C5 query geometry: 800x1200 queries (padded to 800x1216: level widths 152/76/38/19/10, not
+    multiples of the 16-wide halo patches), 337 classes."""
+    from oracle import weights as W
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(W.synthetic_state_dict(0, depth=50))
+    q = W.synthetic_images(3, 800, 1200, seed=31)
+    codes = W.synthetic_codes(337, seed=32, scale=1.5)
+    eng.preprocess(q)
+    eng.backbone()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    dets = eng.decode()
+    assert len(dets) == 3 and all(d["scores"].numel() > 0 for d in dets)
+    pyr = eng.export_pyramid()
+    assert [tuple(p.shape[-2:]) for p in pyr] == [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)]
+    assert all(bool(torch.isfinite(p.float()).all()) for p in pyr)
