@@ -204,14 +204,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
 // the partials of its segment in tile order (deterministic, fp64) and applies the affine (+ReLU).
 // ngroups = C/8 (32 for one tower, 64 for the paired cls|bbox towers held side by side).
 // Finalize: one block per segment folds the conv epilogue's per-tile (n, mean, M2) partials of every group in a
-// fixed order (fp64 Chan merges: 256/ngroups interleaved chains per group, then the chains in index order) and
+// fixed order (fp64 Chan merges: 1024/ngroups interleaved chains per group, then the chains in index order) and
 // leaves (mean, rstd) per (segment, group).  Done once per layer: the fp64 chain (two divisions per tile) is far
 // too slow to repeat in every block of the streaming pass.
-__global__ __launch_bounds__(256) void gn_finalize_partials_kernel(const GnSeg* segs, int ngroups, const float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const GnSeg* segs, int ngroups, const float* __restrict__ partial,
                                                                    float eps, float2* __restrict__ stats) {
   const GnSeg sg = segs[blockIdx.x];
-  const int g = threadIdx.x % ngroups, sub = threadIdx.x / ngroups, nsub = 256 / ngroups;
-  __shared__ double sh[256 * 3];
+  const int g = threadIdx.x % ngroups, sub = threadIdx.x / ngroups, nsub = 1024 / ngroups;
+  __shared__ double sh[1024 * 3];
   double N = 0.0, M = 0.0, Q = 0.0;
   for (int t = sub; t < sg.ntiles; t += nsub) {
     const float* p = partial + ((size_t)(sg.tile0 + t) * ngroups + g) * 3;
@@ -284,7 +284,7 @@ int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg
                              hipStream_t s) {
   if (ngroups != 32 && ngroups != 64) return -1;
   const int rpc = GN_ROWS_PER_CHUNK;
-  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(256), 0, s, segs_dev, ngroups, partial, eps, stats_ws);
+  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(1024), 0, s, segs_dev, ngroups, partial, eps, stats_ws);
   dim3 grid((max_rows + rpc - 1) / rpc, nseg), block(256);
   if (dt == DT_BF16)
     hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, ngroups, rpc, stats_ws, gamma,
