@@ -170,3 +170,29 @@ def inference_on_dataset_with_class_codes(model, data_loader, evaluator, class_c
     _log_totals("query", "img", time.perf_counter() - start_time, compute, total - num_warmup, devices)
     results = evaluator.evaluate()
     return results if results is not None else {}
+
+
+def detections_to_coco_rows(outputs: List[Dict[str, Any]], image_ids: List[int],
+                            contiguous_to_dataset_id: Dict[int, int] = None) -> List[Dict[str, Any]]:
+    """Result sink: COCO-json rows for a whole batch with ONE device->host copy.
+
+    The reference converts per image (`instances_to_coco_json` in the d2 evaluators called from
+    meta_learn_evaluation.py:428,465: one `.to(cpu)` per field per image).  Here the boxes / scores / classes of every
+    image of the batch are concatenated on the device, copied once, and split on the host.  Boxes go from XYXY to the
+    COCO XYWH convention."""
+    assert len(outputs) == len(image_ids)
+    insts = [o["instances"] for o in outputs]
+    counts = [len(i) for i in insts]
+    if sum(counts) == 0:
+        return []
+    packed = torch.cat([torch.cat([i.pred_boxes.tensor.float(), i.scores.float().unsqueeze(1),
+                                   i.pred_classes.float().unsqueeze(1)], dim=1) for i in insts if len(i) > 0]).cpu()
+    rows, k = [], 0
+    for img_id, n in zip(image_ids, counts):
+        blk = packed[k:k + n].tolist()
+        k += n
+        for x0, y0, x1, y1, s, c in blk:
+            cid = int(c)
+            rows.append({"image_id": img_id, "category_id": contiguous_to_dataset_id[cid] if contiguous_to_dataset_id else cid,
+                         "bbox": [x0, y0, x1 - x0, y1 - y0], "score": s})
+    return rows

@@ -215,3 +215,23 @@ def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
         cid = r["support_set_target"]
         np.testing.assert_allclose(r["class_code"]["cls_conv"].numpy(), g[f"reduced{cid}_cls_conv"], atol=1e-6)
     assert res["rows"].shape == (3, D.ROW) and res["rows"][:, D.F_CID].tolist() == [4.0, 5.0, 6.0]
+
+
+def test_detections_to_coco_rows_batches_one_copy():
+    import torch
+    from sylph_amd.evaluation import detections_to_coco_rows
+    from sylph_amd.structures import Boxes, Instances
+
+    def inst(boxes, scores, classes):
+        r = Instances((100, 200))
+        r.pred_boxes = Boxes(torch.tensor(boxes, dtype=torch.float32).reshape(-1, 4))
+        r.scores = torch.tensor(scores, dtype=torch.float32)
+        r.pred_classes = torch.tensor(classes, dtype=torch.int64)
+        return {"instances": r}
+
+    outs = [inst([[1, 2, 11, 22], [0, 0, 5, 5]], [0.9, 0.4], [3, 0]), inst([], [], []), inst([[10, 10, 30, 50]], [0.7], [1])]
+    rows = detections_to_coco_rows(outs, [7, 8, 9], {0: 100, 1: 101, 3: 103})
+    assert [r["image_id"] for r in rows] == [7, 7, 9]
+    assert rows[0]["bbox"] == [1.0, 2.0, 10.0, 20.0] and rows[0]["category_id"] == 103
+    assert rows[2]["bbox"] == [10.0, 10.0, 20.0, 40.0] and abs(rows[2]["score"] - 0.7) < 1e-6
+    assert detections_to_coco_rows([inst([], [], [])], [1]) == []
