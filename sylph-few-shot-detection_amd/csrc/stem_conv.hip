@@ -57,22 +57,32 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const bf16_t* __restr
   // Loads are UNCONDITIONAL (clamped address, value zeroed afterwards) and fetch() runs every iteration (clamped
   // tile): with a static number of loads per tile the compiler can retire a patch with a counted vmcnt instead of
   // vmcnt(0), which would also wait for the previous tile's output stores and for the other patch in flight.
+  // tile-independent per-lane constants of the patch loader and of the epilogue (only the tile origin changes)
+  int f_pr[NLOAD], f_pc[NLOAD], f_lds[NLOAD];
+  uint32_t f_in = 0;
+#pragma unroll
+  for (int r = 0; r < NLOAD; ++r) {
+    const int idx = tid + 256 * r;
+    f_pr[r] = idx / PCOLS; f_pc[r] = idx - f_pr[r] * PCOLS;
+    f_lds[r] = (f_pr[r] * PP + f_pc[r]) * 8;
+    f_in |= (idx < PROWS * PCOLS ? 1u : 0u) << r;
+  }
+
   auto fetch = [&](int tile_in, uint2 (&v)[NLOAD], uint32_t& okmask) {
     const int tile = tile_in < ntiles ? tile_in : ntiles - 1;
     const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y, b = t2 / tiles_y;
     const int iy0 = ty * 16 - 3, ix0 = tx * 32 - 3;
     okmask = 0;
+    const bf16_t* xb = x + (size_t)b * H * W * 4;
 #pragma unroll
     for (int r = 0; r < NLOAD; ++r) {
-      const int idx = tid + 256 * r;
-      const int pr = idx / PCOLS, pc = idx - pr * PCOLS;
-      const int iy = iy0 + pr, ix = ix0 + pc;
-      const bool ok = idx < PROWS * PCOLS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+      const int iy = iy0 + f_pr[r], ix = ix0 + f_pc[r];
+      const bool ok = ((f_in >> r) & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
       // issued through inline asm so that the compiler does not schedule a vmcnt(0) of its own before park():
       // the wait is the counted one in do_tile() (loads retire in order, so <= NLOAD outstanding ops means this
       // patch has landed while the other patch may still be in flight)
-      const bf16_t* src = x + (((size_t)b * H + cy) * W + cx) * 4;
+      const bf16_t* src = xb + (cy * W + cx) * 4;
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v[r]) : "v"(src) : "memory");
       okmask |= (ok ? 1u : 0u) << r;
     }
@@ -80,10 +90,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const bf16_t* __restr
   auto park = [&](const uint2 (&v)[NLOAD], uint32_t okmask) {
 #pragma unroll
     for (int r = 0; r < NLOAD; ++r) {
-      const int idx = tid + 256 * r;
-      const int pr = idx / PCOLS, pc = idx - pr * PCOLS;
       const uint2 t = ((okmask >> r) & 1u) ? v[r] : make_uint2(0u, 0u);
-      if (idx < PROWS * PCOLS) *reinterpret_cast<uint2*>(patch + (pr * PP + pc) * 8) = t;
+      if ((f_in >> r) & 1u) *reinterpret_cast<uint2*>(patch + f_lds[r]) = t;
     }
   };
 
