@@ -21,9 +21,18 @@
 // NBUF = 1: one 128-byte slice resident (LDS (BM+BN)*128 B, two barriers per slice, latency hidden
 // by 3-4 co-resident blocks per CU); NBUF = 2: next slice in flight during the MFMAs.
 //
+// HALO mode (3x3 stride-1 pad-1 layers): the M tile is an 8 x 16 patch of output positions; its 10 x 18 input halo is
+// staged ONCE per 64-channel slice and the nine taps read shifted rows of it, so only the weight tile is fetched per
+// tap (K order: channel slice outer, taps inner).  The halo image is swizzled by halo COLUMN, which keeps a fragment
+// read that spans two patch rows conflict-free.
+//
+// MFMA operands are passed swapped (D^T = W * A^T): a lane then owns 4 consecutive CHANNELS of one position, and the
+// fp32 epilogue tile is written with ds_write_b128.
+//
 // Epilogue (fused): accumulators -> LDS (fp32) -> per lane 8 consecutive channels: per-channel
 // scale/shift (FrozenBN or bias), residual add (optionally through a nearest 2x upsample: the FPN
-// top-down path), per-segment Scale_l, ReLU, 16-byte stores.
+// top-down path), per-segment Scale_l, ReLU, GroupNorm partial statistics, 16-byte stores.  The FAST instantiation
+// (bf16 in/out, full tiles) has a branch-free row loop: the short-K tiles are instruction-issue bound.
 // Reference ops replaced: every F.conv2d / nn.Conv2d on the path: ResNet stem and
 // bottleneck convs + FrozenBN (detectron2), FPN lateral/output/P6/P7, FCOS towers (fcos.py:72-122),
 // bbox_pred/ctrness (fcos.py:656-664), CondConvBasic (head_utils.py:60-81), code-generator
