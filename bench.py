@@ -209,7 +209,7 @@ def pmc_traffic_per_launch(batch, launches_per_step):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (separate runs of this same
     command: FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; tools/rocpd_pmc.py).
     Scaled from the profiled batch to this run's batch (traffic is per image); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_f_pmc_hbm_traffic.json")
     if not os.path.exists(path) or launches_per_step <= 0:
         return None
     with open(path) as f:
