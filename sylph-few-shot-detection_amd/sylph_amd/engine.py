@@ -262,7 +262,16 @@ class Engine:
         check(self.L.sylph_decode_nms(self._ctx, oh, ow, max_out, _ptr(boxes), _ptr(scores), _ptr(classes),
                                       _ptr(levels), _ptr(locs), _ptr(cand), _ptr(counts),
                                       c_void_p(counts.data_ptr() + 4 * B)), "decode_nms")
-        host_counts = torch.empty(B + 1, dtype=torch.int32, pin_memory=True)
+        # pinned staging for the counts: a small per-engine ring (a fresh pinned allocation per step costs milliseconds
+        # of host time, which is the whole step at batch 1)
+        ring = self.__dict__.setdefault("_count_ring", {})
+        slot = ring.setdefault(B, {"bufs": [], "next": 0})
+        if len(slot["bufs"]) < 8:
+            slot["bufs"].append(torch.empty(B + 1, dtype=torch.int32, pin_memory=True))
+            host_counts = slot["bufs"][-1]
+        else:
+            host_counts = slot["bufs"][slot["next"] % 8]
+            slot["next"] += 1
         host_counts.copy_(counts, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
