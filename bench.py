@@ -159,6 +159,20 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     prof = eng.profile_read()
+    # Split of the conv time into backbone+FPN and head (BASELINE's second metric: "backbone MFMA %peak"): three
+    # extra UNTIMED, unpipelined steps with a sync between the two stages (the split needs a readback per stage).
+    split = {"backbone_ms": 0.0, "backbone_flops": 0.0, "head_ms": 0.0, "head_flops": 0.0}
+    if not args.no_kernel_events:
+        for _ in range(3):
+            eng.preprocess(queries)
+            eng.backbone()
+            torch.cuda.synchronize()
+            p1 = eng.profile_read()
+            eng.head(cls_conv, cls_bias)
+            torch.cuda.synchronize()
+            p2 = eng.profile_read()
+            split["backbone_ms"] += p1["conv_ms"]; split["backbone_flops"] += p1["conv_flops"]
+            split["head_ms"] += p2["conv_ms"]; split["head_flops"] += p2["conv_flops"]
     eng.profile_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -184,6 +198,12 @@ def main():
             "gflop_counted_by_library_per_image": round(prof["conv_flops"] / images_timed / 1e9, 2),
             "conv_share_of_step_time": round(conv_s / elapsed, 3),
         }
+        if split["backbone_ms"] > 0 and split["head_ms"] > 0:
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            bb = split["backbone_flops"] / (split["backbone_ms"] * 1e-3) / 1e12
+            hd = split["head_flops"] / (split["head_ms"] * 1e-3) / 1e12
+            roofline["backbone_fpn"] = {"achieved": round(bb, 2), "frac": round(bb / peak, 4), "gflop_per_image": round(split["backbone_flops"] / (3 * B) / 1e9, 2)}
+            roofline["head"] = {"achieved": round(hd, 2), "frac": round(hd / peak, 4), "gflop_per_image": round(split["head_flops"] / (3 * B) / 1e9, 2)}
         out = {
             "metric": "query images/sec, R50-FPN 5-way 5-shot 800x1333 (whole job)", "value": round(value, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
