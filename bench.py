@@ -189,7 +189,7 @@ def main():
         alg_flops = GFLOP_PER_IMAGE_MFMA_CONV * 1e9 * images_timed  # all conv launches of the region, this rank
         achieved = alg_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         roofline = {
-            "kernel": "conv_igemm_kernel (+ stem_conv_kernel): implicit-GEMM MFMA convs, all 63 launches per step of the timed region",
+            "kernel": "conv_igemm_kernel (+ stem_conv_kernel): implicit-GEMM MFMA convs, every conv launch of the timed region",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
             "traffic": pmc_traffic_per_launch(B, launches // max(args.steps, 1)),

@@ -1181,7 +1181,9 @@ int sylph_finalize_weights(sylph_ctx* c) {
       RET(make_gn(c, hp + ".bbox_tower." + std::to_string(3 * i + 1), &c->box_gn[i]));
     }
     const char* pz = getenv("SYLPH_PAIR_TOWERS");
-    if (c->cfg.num_cls_convs == c->cfg.num_box_convs && c->cfg.num_cls_convs > 0 && !(pz && atoi(pz) == 0)) {
+    // Pairing (both towers as ONE grouped launch per layer) paid +2 % with the pre-halo kernel (the A tile was shared by
+    // four N tiles); with halo tiles the separate towers are 1 % faster (1 666-1 672 vs 1 645-1 660 img/s), so it is opt-in.
+    if (c->cfg.num_cls_convs == c->cfg.num_box_convs && c->cfg.num_cls_convs > 0 && (pz && atoi(pz) == 1)) {
       // run both towers as ONE launch per layer: outputs side by side ([rows][512] = cls | bbox)
       const int n = c->cfg.num_cls_convs;
       c->pair_tower.resize(n); c->pair_gn.resize(n);
