@@ -87,7 +87,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from oracle import weights as W  # synthetic weights/inputs only (no model arithmetic)
+    from sylph_amd import synthetic as W  # seeded synthetic weights / inputs (pure data generation)
     from sylph_amd import distributed as D
     from sylph_amd.engine import Engine
 

@@ -20,4 +20,4 @@ reference (hand-derived known-answer cases in tests/ only).
 Every function cites the reference file:line (paths relative to /root/reference) it follows.
 """
 
-from . import backbone, codegen, decode, episode, head, roi_align, roi_encoder, weights  # noqa: F401
+from . import backbone, codegen, decode, episode, head, roi_align, roi_encoder  # noqa: F401

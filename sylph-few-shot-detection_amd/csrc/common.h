@@ -23,6 +23,9 @@ struct SegDesc {
   int res_row0, res_H, res_W;  // residual source geometry (res_mode 2: half resolution)
   float mul;                   // per-segment multiplier (FCOS Scale_l), applied to channels < mul_nch
   int in2_row0, in2_W;         // second input (dual-source pointwise conv): first row, row width
+  int ph, pw;                  // halo-tile mode: patch height / width of this segment (ph * pw <= M tile rows)
+  int hpitch;                  // halo-tile mode: LDS rows per halo row (pw + 2; conv_hpipe.hip: pw + 4, see there)
+  unsigned inv_pw, inv_hw2;    // ceil(65536 / pw), ceil(65536 / hpitch): n / d == (n * inv) >> 16 for n < 256
 };
 
 struct ConvArgs {
@@ -45,7 +48,7 @@ struct ConvArgs {
   int mul_nch;                // seg.mul on output channels < mul_nch
   int res_mode;               // 0 none, 1 same geometry, 2 nearest-neighbour 2x upsample of res
   float* gn_partial;          // optional [n_mtiles][Cout/8][3] per-tile GroupNorm partials (n, mean, M2)
-  int halo;                   // 3x3 s1 p1 halo-tile mode: tiles[].y = (patch row << 16) | patch col (8 x 16 patches)
+  int halo;                   // 3x3 s1 p1 halo-tile mode: tiles[].y = (patch row << 16) | patch col (seg.ph x seg.pw patches)
   int res_lds;                // set by launch_conv: residual tile staged through LDS
   int ss_padded_host;         // as given by the caller (ss_padded is cleared for wide tiles)
   int ss_padded;              // scale/shift arrays are padded to a multiple of the N tile (vector prefetch allowed)
@@ -102,10 +105,12 @@ __device__ __forceinline__ void lds_barrier() {
 // ---- launcher prototypes (one per translation unit) -----------------------------------------
 // conv_igemm.hip
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);
-void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN, bool pipe_ok = false);
-// conv_pipe.hip: 256x256 deep-pipelined variant (BM == BN == 256 selects it in launch_conv)
-bool conv_pipe_ok(DType dt, bool out_f32, const ConvArgs& a);
-int launch_conv_pipe(const ConvArgs& a, hipStream_t s);
+void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
+// conv_hpipe.hip: 256x256 deep-pipelined halo-operand 3x3 kernel (BM == BN == 256 selects it in launch_conv; the tile
+// table then holds PAIRS of patches and n_mtiles counts the pairs)
+bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a);
+int launch_conv_hpipe(const ConvArgs& a, hipStream_t s);
+int launch_hpipe_pack_weights(const void* w_igemm, void* w_hpipe, int Cout, int Cin, hipStream_t s);  // a.wt of an hpipe launch
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 
 }  // namespace sylph

@@ -1,0 +1,429 @@
+// Deep-pipelined 3x3 (stride 1, pad 1) implicit-GEMM convolution with a HALO A operand, for the MFMA-bound layers
+// (FCOS towers fcos.py:72-122, FPN output convs, bottleneck conv2 of res4/res5).
+//
+// One 512-thread block per CU owns a 256 (positions) x 256 (channels) output tile.  The 256 positions are TWO
+// independent ph x pw patches (<= 128 positions each, shapes picked per pyramid level on the host: 10 x 12 on the
+// 100 x 168 / 50 x 84 maps), one per wave row:
+//
+//   * 8 waves = 2 (patch) x 4 (64-channel column); wave tile 128 x 64 = 4 x 2 MFMA 32x32x16 tiles (128 accumulator
+//     VGPRs): 12 ds_read_b128 per 16 MFMAs.
+//   * K order: 32-channel half-slice outer, the 9 taps inner.  A operand: the (ph+2) x (pw+2) input halo of each patch
+//     for one half-slice (64-byte rows) is fetched ONCE and all nine taps read shifted rows of it, so the only per-tap
+//     traffic is the weight tile (256 rows x 64 B = 16 KiB): L2->LDS bytes per flop are 0.58x those of a plain
+//     256x256 GEMM tile (the round-1 conv_pipe kernel starved on exactly that stream) and 0.36x those of the
+//     128x128 halo kernel.
+//   * LDS: four 16-KiB weight stages (ring) + two 32-KiB halo buffers (double buffer) = 128 KiB.  The weight tile of
+//     phase q+3 and (during taps 0..3) one quarter of the next half-slice's halo are issued by global_load_lds right after
+//     the fragment reads of phase q and waited for two phases later with a COUNTED s_waitcnt vmcnt(N): never a drain in
+//     the steady state.  The 9 taps are unrolled, so every N and every tap offset is an immediate.  The loads sit in the
+//     L (fragment read) segment, whose instruction stream has the slack; the M segment is 16 bare MFMAs.  Load addresses
+//     cost no VALU work: weights use a wave-uniform base + a constant per-lane offset, the halo running per-lane pointers.
+//   * The two wave rows (the two waves that share a SIMD) run staggered by one barrier: while one issues its 16
+//     MFMAs (s_setprio 1) the other does its fragment reads and address arithmetic.  Raw s_barrier + explicit
+//     waitcnts only (a __syncthreads would drain the LDS-DMA queue).
+//
+// Hazards (B_n = n-th barrier, seg n = between B_n and B_n+1; row 0 does L(q) in seg 2q and M(q) in seg 2q+1, row 1 one
+// segment later):
+//   RAW  weight stage of phase q+1 (issued in L(q-2)) is read from seg 2q+2 on; both rows execute their vmcnt wait for
+//        their own phase-(q+1) loads in seg 2q+1 (row 0 at the end of M(q), row 1 at the end of L(q)), i.e. before B_{2q+2}.
+//        The halo of half-slice c+1 is issued in L(c,0..3); the in-order vmcnt waits of phases (c,4..6) retire it long
+//        before L(c+1,0).
+//   WAR  stage (q-1)&3 (and, at tap 0, the halo buffer last read in L(q-1)) is refilled by row 0 in seg 2q and by row 1 in
+//        seg 2q+1; the last reader (row 1, L(q-1), seg 2q-1) retires its ds_reads with lgkmcnt(0) before B_{2q}.
+//
+// Weights are RE-PACKED for this kernel (hpipe_pack_weights_kernel, once per layer): [n tile][half-slice][tap] -> one
+// contiguous 16-KiB block that already is the LDS image of a stage.  With the generic [n][kh][kw][c] layout the 256 rows of
+// a phase sit 4 608 B apart: every phase touched the same 4 of the 16 L2 channels, in half cache lines, from all CUs at
+// once, and the kernel ran 32 % slower than with the loads removed.  Now a stage is a linear 16-KiB copy (128 full lines
+// over all channels).  Blocks also start the K loop at different half-slices (rotation by tile index), which spreads the
+// 64-byte-per-512-byte halo rows of concurrently running blocks over the channels.
+//
+// LDS images (lane-linear global_load_lds, swizzle on the SOURCE side, same XOR on the fragment reads):
+//   weights [256 rows][64 B]: slot s of row r holds 16-byte chunk s ^ ((r >> 2) & 3) (applied by the re-pack);
+//   halo    [2 patches][256 rows][64 B], row h = hy * (pw + 4) + hx: slot s holds chunk s ^ ((k >> 2) & 3), k = hy * pw + hx.
+//           The reader of tap (kh, kw) at patch position m sits on k = m + kh * pw + kw; the 16 lanes of a ds_read_b128
+//           group ({0-3, 12-15, 20-27} + ...) hold 16 distinct k mod 16.  The 16-byte bank slot of a read is
+//           (h & 3) * 4 + slot, and with the pitch pw + 4 (two unused entries per halo row) h = k + 4 hy, so it depends on
+//           k mod 16 only: conflict-free for every patch shape.  (Pitch pw + 2 made it depend on the parity of hy: measured
+//           35 % of all LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)
+//
+// Scope (launch_conv checks): bf16 in/out, 3x3 s1 p1, no residual, no per-segment Scale, ReLU on all channels or none,
+// Cout % 256 == 0, Cin % 32 == 0, padded scale/shift; optional fused GroupNorm partial statistics (one per patch).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace sylph {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+namespace {
+constexpr int PNT = 512;
+constexpr int BSTAGE = 256 * 64;               // one weight stage: 256 output channels x 32 input channels
+constexpr int NSTAGE = 4;
+constexpr int HPROWS = 256;                    // halo rows reserved per patch
+constexpr int HBUF = 2 * HPROWS * 64;          // one halo buffer (both patches)
+constexpr int HALO_OFF = NSTAGE * BSTAGE;
+constexpr int LDS_BYTES = HALO_OFF + 2 * HBUF;  // 131 072
+constexpr int SCP = 256 + 4;                   // fp32 pitch of the epilogue tile
+static_assert(64 * SCP * 4 <= LDS_BYTES, "epilogue tile must fit");
+
+// loads a wave issues in the L segment of tap t: the two weight halves of phase q+3, plus one halo piece on taps 0..3
+constexpr int NPIECE = 2 * HPROWS / 128;  // block-wide halo loads per half-slice (taps 0..3 carry one each)
+constexpr int nload(int t) { return ((t % 9 + 9) % 9) < NPIECE ? 3 : 2; }
+
+#define HP_SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
+#define HP_BAR()                                   \
+  do {                                             \
+    asm volatile("" ::: "memory");                 \
+    HP_SCHED_FENCE;                                \
+    __builtin_amdgcn_s_barrier();                  \
+    HP_SCHED_FENCE;                                \
+    asm volatile("" ::: "memory");                 \
+  } while (0)
+#ifdef HP_NOWAITV
+#define HP_WAITV(N) asm volatile("" ::: "memory")
+#else
+#define HP_WAITV(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#endif
+#define HP_WAITL() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+}  // namespace
+
+__global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware block -> tile map (as conv_igemm.hip); an M tile is a PAIR of patches
+  const int L = blockIdx.x;
+  const int xcd = L & 7, q0 = L >> 3;
+  const int chunk = (a.n_mtiles + 7) >> 3;
+  const int m_local = q0 / a.n_ntiles;
+  const int nt = q0 - m_local * a.n_ntiles;
+  const int mt = xcd * chunk + m_local;
+  if (m_local >= chunk || mt >= a.n_mtiles) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int2 tl0 = a.tiles[2 * mt], tl1 = a.tiles[2 * mt + 1];
+  const SegDesc sd0 = a.segs[tl0.x], sd1 = a.segs[tl1.x];
+
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+  const T* __restrict__ zero = reinterpret_cast<const T*>(a.zeros);
+  const int Cin = a.Cin;
+  const int ncc = Cin >> 5;  // 32-channel half-slices
+  const int goff = a.group_cout > 0 ? ((nt * 256) / a.group_cout) * a.group_in_off : 0;
+  // K-loop rotation: this block walks the half-slices c0, c0+1, ... (mod ncc)
+  const int c0 = (mt + nt) % ncc;
+
+  // ---- loader state --------------------------------------------------------------------------------------------
+  // lane (r4, s4) of a block-wide global_load_lds fetches 16-byte slot s4 of LDS row (round * 128 + r4)
+  const int r4 = tid >> 2, s4 = tid & 3;
+  // halo: LDS rows [0, 256) patch 0, [256, 512) patch 1; four rounds of 128 rows, halo row (hy, hx) at hy * hpitch + hx.
+  // Each lane keeps a running 64-bit source pointer per halo piece (advanced by 64 B per half-slice; lanes outside the
+  // image / past the halo stay on the zero page), so issuing a piece costs no VALU work.
+  const char* hptr[NPIECE];
+  unsigned hmask = 0;
+#pragma unroll
+  for (int g = 0; g < NPIECE; ++g) {
+    const bool p1 = g >= NPIECE / 2;
+    const SegDesc& sd = p1 ? sd1 : sd0;
+    const int ty = p1 ? tl1.y : tl0.y;
+    const int h = g * 128 + r4 - (p1 ? HPROWS : 0);
+    const int PW = sd.pw, HP = sd.hpitch, HR = (sd.ph + 2) * HP;
+    const int hy = (int)(((unsigned)h * sd.inv_hw2) >> 16), hx = h - hy * HP;
+    const int iy = (ty >> 16) - 1 + hy, ix = (ty & 0xffff) - 1 + hx;
+    const bool ok = h < HR && hx < PW + 2 && (unsigned)iy < (unsigned)sd.in_H && (unsigned)ix < (unsigned)sd.in_W;
+    const int cs = s4 ^ (((hy * PW + hx) >> 2) & 3);
+    hptr[g] = ok ? reinterpret_cast<const char*>(in + ((size_t)(sd.in_row0 + iy * sd.in_W + ix) * a.in_ld + cs * 8 + goff + c0 * 32))
+                 : reinterpret_cast<const char*>(zero + s4 * 8);
+    hmask |= (ok ? 1u : 0u) << g;
+  }
+  // weights: stage image of (n tile, half-slice c, tap t) = 16 KiB at ((nt * ncc + c) * 9 + t) * 16 KiB; lane copies
+  // bytes [tid * 16, +16) of each 8-KiB half: wave-uniform base (SALU) + a constant per-lane offset
+  const char* const wtile = reinterpret_cast<const char*>(wt) + (size_t)nt * ncc * 9 * BSTAGE;
+  const unsigned wvo = (unsigned)tid * 16u;
+  bool loads_on = true;  // ablation builds (HP_NOLOAD) switch the main-loop loads off after a prologue that fills every stage
+  auto issue_halo = [&](int g, int buf) {  // piece g of the half-slice the running pointers stand on -> halo buffer buf
+    if (!loads_on) return;
+    {
+    char* d = smem + HALO_OFF + buf * HBUF + g * 8192 + wave * 1024;  // wave-uniform; lane l lands at +16 l
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)hptr[g], (lds_ptr_t)d, 16, 0, 0);
+    }
+  };
+  // step the halo pointers to the next half-slice of the rotated walk (wrap: back by Cin - 32 channels)
+  auto advance_halo = [&](int cc_next) {
+    const int step = (c0 + cc_next == ncc) ? (32 - Cin) * 2 : 64;  // wave-uniform
+#pragma unroll
+    for (int g = 0; g < NPIECE; ++g) hptr[g] += ((hmask >> g) & 1u) ? step : 0;
+  };
+  auto issue_w = [&](int stage, int j, int blk) {  // 8-KiB half j of weight block blk (= rotated half-slice * 9 + tap)
+    if (!loads_on) return;
+    {
+    char* d = smem + stage * BSTAGE + j * 8192 + wave * 1024;
+    const char* src = wtile + (size_t)blk * BSTAGE + j * 8192 + wvo;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)d, 16, 0, 0);
+    }
+  };
+  auto rot = [&](int cc) { const int c = c0 + cc; return c >= ncc ? c - ncc : c; };
+
+  // ---- fragment addressing -----------------------------------------------------------------------------------------
+  const SegDesc& sdm = wm ? sd1 : sd0;  // this wave row's patch
+  const int PWm = sdm.pw, HW2m = sdm.hpitch;
+  int a0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = i * 32 + l31;
+    const int my = (int)(((unsigned)m * sdm.inv_pw) >> 16);
+    a0[i] = (wm * HPROWS + my * HW2m + (m - my * PWm)) * 64;
+  }
+  int offB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) offB[ks] = (wn * 64 + l31) * 64 + (((ks * 2 + lh) ^ ((l31 >> 2) & 3)) << 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8 fa[2][4], fb[2][2];
+
+  // L(cc, t): the 12 fragment reads of tap t of half-slice cc
+  auto ldfrag = [&](int cc, int t) {
+    const int kh = t / 3, kw = t - 3 * kh;
+    const char* bs = smem + ((cc + t) & 3) * BSTAGE;  // phase q = 9 cc + t; q & 3 == (cc + t) & 3
+    const char* hs = smem + HALO_OFF + (cc & 1) * HBUF + (kh * HW2m + kw) * 64;
+    const int f = ((l31 + kh * PWm + kw) >> 2) & 3;
+#ifdef HP_NOLDS
+    if (cc + t > 0) return;
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = ((ks * 2 + lh) ^ f) << 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(bs + offB[ks] + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(hs + a0[i] + so);
+    }
+  };
+
+  // The loads of phase q+3 = tap t+3 (weights into stage (q+3) & 3) and, on taps 0..2, piece t of the next half-slice's
+  // halo.  Issued in the L segment, after the fragment reads: the other wave row is in its MFMA segment meanwhile.
+  // Past the last phase the weight loads re-read K offset 0 into a stage nobody reads any more (constant load count).
+  auto issue_next = [&](int cc, int t) {
+    const int t3 = (t + 3) % 9, cc3 = cc + (t + 3) / 9;
+    const int blk = cc3 < ncc ? rot(cc3) * 9 + t3 : 0;
+    const int st3 = (cc + t + 3) & 3;
+    if (t == 0 && cc + 1 < ncc) advance_halo(cc + 1);  // the pointers now stand on (rotated) half-slice cc + 1; the last one is re-read at the end: harmless
+    if (t < NPIECE) issue_halo(t, (cc + 1) & 1);
+    issue_w(st3, 0, blk);
+    issue_w(st3, 1, blk);
+  };
+  // M(cc, t): 16 back-to-back MFMAs
+  auto mma = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);  // D^T
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: halo of half-slice 0 and the weights of phases 0..2 ---------------------------------------------
+#pragma unroll
+  for (int g = 0; g < NPIECE; ++g) issue_halo(g, 0);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    issue_w(t, 0, c0 * 9 + t);
+    issue_w(t, 1, c0 * 9 + t);
+  }
+#ifdef HP_NOLOAD
+  issue_w(3, 0, c0 * 9 + 3); issue_w(3, 1, c0 * 9 + 3);
+  for (int g = 0; g < NPIECE; ++g) issue_halo(g, 1);
+  HP_WAITV(0);
+  loads_on = false;
+#endif
+  HP_WAITV(4);  // halo + phase 0 landed (phases 1, 2 in flight)
+  HP_BAR();     // B_0
+
+  // vmcnt immediates: a wave needs its loads of phase q+1 (issued in L(q-2)) landed before B_{2q+2}; the loads issued after
+  // them are the groups of L(q-1) and L(q).  Row 0 waits at the end of M(q) (seg 2q+1), row 1 at the end of L(q) (seg 2q+1).
+#define HP_PHASE0(t)                      \
+  ldfrag(cc, t);                          \
+  HP_SCHED_FENCE;                         \
+  issue_next(cc, t);                      \
+  HP_WAITL();                             \
+  HP_BAR();                               \
+  mma();                                  \
+  HP_WAITV(nload((t) - 1) + nload(t));    \
+  HP_BAR();
+#define HP_PHASE1(t)                      \
+  ldfrag(cc, t);                          \
+  HP_SCHED_FENCE;                         \
+  issue_next(cc, t);                      \
+  HP_WAITV(nload((t) - 1) + nload(t));    \
+  HP_WAITL();                             \
+  HP_BAR();                               \
+  mma();                                  \
+  HP_BAR();
+
+  if (wm == 0) {
+    for (int cc = 0; cc < ncc; ++cc) {
+      HP_PHASE0(0) HP_PHASE0(1) HP_PHASE0(2) HP_PHASE0(3) HP_PHASE0(4) HP_PHASE0(5) HP_PHASE0(6) HP_PHASE0(7) HP_PHASE0(8)
+    }
+    HP_BAR();
+  } else {
+    HP_BAR();  // the stagger
+    for (int cc = 0; cc < ncc; ++cc) {
+      HP_PHASE1(0) HP_PHASE1(1) HP_PHASE1(2) HP_PHASE1(3) HP_PHASE1(4) HP_PHASE1(5) HP_PHASE1(6) HP_PHASE1(7) HP_PHASE1(8)
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-page tail loads must not land in the epilogue tile
+  __syncthreads();
+
+  // ---- fused epilogue: per patch two 64-row passes through an fp32 LDS tile ---------------------------------------
+  float* const sC = reinterpret_cast<float*>(smem);
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+  const int c8 = tid & 31, rr = tid >> 5;
+  const int n0 = nt * 256 + c8 * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 s4v = a.scale ? reinterpret_cast<const float4*>(a.scale + n0)[h] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 b4v = a.shift ? reinterpret_cast<const float4*>(a.shift + n0)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[4 * h] = s4v.x; sc[4 * h + 1] = s4v.y; sc[4 * h + 2] = s4v.z; sc[4 * h + 3] = s4v.w;
+    sh[4 * h] = b4v.x; sh[4 * h + 1] = b4v.y; sh[4 * h + 2] = b4v.z; sh[4 * h + 3] = b4v.w;
+  }
+  const bool relu = a.relu_nch > 0;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {  // patch
+    const SegDesc& sp = pp ? sd1 : sd0;
+    const int ty = pp ? tl1.y : tl0.y;
+    const int oy0 = ty >> 16, ox0 = ty & 0xffff;
+    const int PW = sp.pw, NPOS = sp.ph * sp.pw;
+    bf16_t* __restrict__ outn = out + (size_t)sp.out_row0 * a.out_ld + n0;
+    // GroupNorm partial sums of this patch about a pivot every lane of a group shares (the conv bias of the group's first
+    // channel: what makes |mean| >> sigma in practice), so that lanes and waves merge by plain additions
+    float gn_n = 0.f, gn_s1 = 0.f, gn_s2 = 0.f;
+    const float gn_pv = sh[0];
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {  // 64-row half of the patch
+      if (pp + hp > 0) lds_barrier();
+      if (wm == pp) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x16& c = acc[2 * hp + ii][j];
+              *reinterpret_cast<float4*>(sC + (ii * 32 + l31) * SCP + wn * 64 + j * 32 + 8 * g + 4 * lh) =
+                  make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+            }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int rl = rr + 16 * it;
+        const int m = hp * 64 + rl;
+        const int my = (int)(((unsigned)m * sp.inv_pw) >> 16);
+        const int oy = oy0 + my, ox = ox0 + (m - my * PW);
+        if (m < NPOS && oy < sp.out_H && ox < sp.out_W) {
+          float v[8];
+          const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (a.gn_partial) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - gn_pv; gn_s1 += d; gn_s2 = fmaf(d, d, gn_s2); }
+            gn_n += 8.f;
+          }
+#ifndef HP_NOEPI
+          store8<bf16_t>(outn + (size_t)(oy * sp.out_W + ox) * a.out_ld, v);
+#else
+          if (v[0] == 1234.5f) store8<bf16_t>(outn + (size_t)(oy * sp.out_W + ox) * a.out_ld, v);
+#endif
+        }
+      }
+    }
+    if (a.gn_partial) {  // one (n, mean, M2) partial per patch and 8-channel group, merged in a fixed order
+      gn_n += __shfl_xor(gn_n, 32);  // lanes c8 and c8 + 32 of a wave hold the same group (rows rr, rr + 1)
+      gn_s1 += __shfl_xor(gn_s1, 32);
+      gn_s2 += __shfl_xor(gn_s2, 32);
+      lds_barrier();
+      float* red = sC;  // [8 waves][32 groups][3]
+      if (lane < 32) {
+        red[(wave * 32 + c8) * 3 + 0] = gn_n;
+        red[(wave * 32 + c8) * 3 + 1] = gn_s1;
+        red[(wave * 32 + c8) * 3 + 2] = gn_s2;
+      }
+      lds_barrier();
+      if (tid < 32) {
+        float N = 0.f, S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          N += red[(w * 32 + c8) * 3 + 0]; S1 += red[(w * 32 + c8) * 3 + 1]; S2 += red[(w * 32 + c8) * 3 + 2];
+        }
+        const float inv_n = N > 0.f ? 1.f / N : 0.f;
+        const float m2 = S2 - S1 * S1 * inv_n;
+        float* gp = a.gn_partial + ((size_t)(2 * mt + pp) * (a.Cout >> 3) + (n0 >> 3)) * 3;
+        gp[0] = N; gp[1] = gn_pv + S1 * inv_n; gp[2] = m2 > 0.f ? m2 : 0.f;
+      }
+    }
+  }
+}
+
+// [Cout][3][3][Cin] bf16 (conv_igemm layout) -> [Cout / 256][Cin / 32][9][256 rows][4 slots][8] with the stage swizzle applied
+__global__ void hpipe_pack_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk
+  const size_t nchunks = (size_t)Cout * 9 * Cin / 8;
+  if (i >= nchunks) return;
+  const int ncc = Cin >> 5;
+  const int s = (int)(i & 3), r = (int)((i >> 2) & 255);
+  const size_t blk = i >> 10;
+  const int t = (int)(blk % 9), c = (int)((blk / 9) % ncc), nt = (int)(blk / (9 * (size_t)ncc));
+  const int chunk = s ^ ((r >> 2) & 3);
+  const uint4 v = *reinterpret_cast<const uint4*>(w + ((size_t)(nt * 256 + r) * 9 + t) * Cin + c * 32 + chunk * 8);
+  *reinterpret_cast<uint4*>(out + i * 8) = v;
+}
+
+int launch_hpipe_pack_weights(const void* w, void* out, int Cout, int Cin, hipStream_t s) {
+  const size_t nchunks = (size_t)Cout * 9 * Cin / 8;
+  hipLaunchKernelGGL(hpipe_pack_weights_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)out, Cout, Cin);
+  return (int)hipGetLastError();
+}
+
+bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a) {
+  return dt == DT_BF16 && !out_f32 && !a.stem && !a.in2 && a.res_mode == 0 && a.mul_nch == 0 && a.KH == 3 && a.KW == 3 &&
+         a.stride == 1 && a.pad == 1 && (a.relu_nch == 0 || a.relu_nch >= a.Cout) && a.Cout % 256 == 0 && a.Cin % 32 == 0 &&
+         a.Cin >= 32 && a.ss_padded_host && (a.out_ld & 7) == 0 && a.zeros != nullptr;
+}
+
+int launch_conv_hpipe(const ConvArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_hpipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
+    attr_set = true;
+  }
+  const int chunk = (a.n_mtiles + 7) / 8;
+  const int grid = 8 * chunk * a.n_ntiles;
+  hipLaunchKernelGGL(conv_hpipe_kernel, dim3(grid), dim3(PNT), LDS_BYTES, s, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace sylph

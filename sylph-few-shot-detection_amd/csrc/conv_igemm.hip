@@ -119,10 +119,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   constexpr int AR = BM / RS, BR = BN / RS;  // wave-level loads per slice (8 rows each)
   // HALO (3x3 s1 p1): the M tile is an 8 x 16 patch of output positions; its 10 x 18 input halo (192 LDS rows with the
   // tail of the last load round) is loaded ONCE per 64-channel slice and the 9 taps read shifted rows of it.
-  constexpr int HPW = 16, HPH = BM / HPW, HW2 = HPW + 2, HROWS = (HPH + 2) * HW2, HRND = (HROWS + NT / 8 - 1) / (NT / 8);
-  constexpr int HALLOC = (HROWS + 7) / 8 * 8;  // rows written: whole 8-row wave loads up to the last real halo row
+  // The patch shape (ph x pw <= BM positions, (ph + 2) * (pw + 2) <= HALLOC halo rows) is chosen per segment on the host
+  // (sylph_api.hip pick_patch: 10 x 12 for the 100 x 168 / 50 x 84 maps, 8 x 16 for 200 x 336, ...).
+  constexpr int HALLOC = 184;                          // LDS rows reserved for the halo (whole 8-row wave loads)
+  constexpr int HRND = (HALLOC + NT / 8 - 1) / (NT / 8);
   constexpr int STAGE = HALO ? (BN + HALLOC) * 128 : (BM + BN) * 128;
-  static_assert(!HALO || (NBUF == 1 && (BM == 128 || BM == 256)), "halo mode: 8x16 or 16x16 patches, single stage");
+  static_assert(!HALO || (NBUF == 1 && BM == 128), "halo mode: 128-position patches, single stage");
   static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,6 +148,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   const SegDesc sd = a.segs[tile.x];
   const int seg_rows = sd.out_H * sd.out_W;
   const int oy0 = HALO ? (tile.y >> 16) : 0, ox0 = HALO ? (tile.y & 0xffff) : 0;  // HALO: tile.y packs the patch origin
+  // HALO patch geometry (wave-uniform).  Divisions by pw / pw + 2 of values < 256 use a 16-bit reciprocal (exact there).
+  const int HPW = HALO ? sd.pw : 16, HW2 = HALO ? sd.hpitch : 18, HROWS = HALO ? (sd.ph + 2) * HW2 : 0, HPOS = HALO ? sd.ph * sd.pw : 0;
+  const unsigned inv_pw = sd.inv_pw, inv_hw2 = sd.inv_hw2;
 
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
   const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
@@ -216,19 +221,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 #pragma unroll
     for (int t = 0; t < HRND; ++t) {
       const int hrow = t * RS + r0;
-      const int hy = hrow / HW2, hx = hrow - hy * HW2;
+      const int hy = (int)(((unsigned)hrow * inv_hw2) >> 16), hx = hrow - hy * HW2;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)sd.in_H && (unsigned)ix < (unsigned)sd.in_W;
-      // bank swizzle keyed on the halo COLUMN: a fragment read covers 16 consecutive columns spread over two
-      // halo rows (8 x 16 patch rows are 18 apart), and 18 is even, so (hx & 1, (hx >> 1) & 7) is conflict-free
-      const int clh = c16 ^ ((hx >> 1) & 7);
+      // bank swizzle keyed on k = hy * pw + hx: the reader of tap (kh, kw) at patch position m sits on k = m + kh * pw + kw,
+      // so the 16 lanes of a ds_read_b128 group (16 consecutive m) see 16 distinct k mod 16, and k has the parity of the
+      // halo row index (row - k = 2 * hy): (row & 1, (k >> 1) & 7) is a distinct 16-byte bank slot for every lane
+      const int clh = c16 ^ (((hy * HPW + hx) >> 1) & 7);
       hsrc[t] = (sd.in_row0 + iy * sd.in_W + ix) * a.in_ld + clh * EPC + goff_h;
       hmask |= (ok ? 1u : 0u) << t;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = wm * WTM + i * 32 + (lane & 31);
-      hb[i] = (m / HPW) * HW2 + (m % HPW);  // (m % HPW) == (lane & 15) for every i
+      const int my = (int)(((unsigned)m * inv_pw) >> 16);
+      hb[i] = my * HW2 + (m - my * HPW);
     }
   }
   if (a.group_cout > 0) {  // grouped conv: this N tile's group reads its own input-channel window
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
 
   if (NBUF == 1) {
     for (int kt = 0; kt < nk; ++kt) {
-      const int hoff = ((kh * HW2 + kw) << 8) | kw;  // halo row offset (and column shift) of the tap about to be fetched
+      const int hoff = ((kh * HW2 + kw) << 8) | ((kh * HPW + kw) & 15);  // halo row offset (and swizzle-key shift) of the tap about to be fetched
       issue(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -443,9 +450,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
         int pos = tile.y + p * WTM + rl;
         bool pv = pos < seg_rows;
         if constexpr (HALO) {
-          const int m = p * WTM + rl, oy = oy0 + m / HPW, ox = ox0 + m % HPW;
+          const int m = p * WTM + rl, my = (int)(((unsigned)m * inv_pw) >> 16);
+          const int oy = oy0 + my, ox = ox0 + (m - my * HPW);
           pos = oy * sd.out_W + ox;
-          pv = oy < sd.out_H && ox < sd.out_W;
+          pv = m < HPOS && oy < sd.out_H && ox < sd.out_W;
         }
         posv[it] = pos;
         pvv[it] = (WTM % RPP == 0 || rl < WTM) && pv;
@@ -521,8 +529,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     for (int rl = rr; rl < WTM; rl += RPP) {
       int pos = tile.y + p * WTM + rl;
       if constexpr (HALO) {
-        const int m = p * WTM + rl, oy = oy0 + m / HPW, ox = ox0 + m % HPW;
-        if (oy >= sd.out_H || ox >= sd.out_W) continue;
+        const int m = p * WTM + rl, my = (int)(((unsigned)m * inv_pw) >> 16);
+        const int oy = oy0 + my, ox = ox0 + (m - my * HPW);
+        if (m >= HPOS || oy >= sd.out_H || ox >= sd.out_W) continue;
         pos = oy * sd.out_W + ox;
       } else {
         if (pos >= seg_rows) break;
@@ -594,7 +603,7 @@ template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF,
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  const size_t stage = HALO ? (size_t)(BN + (BM == 256 ? 328 : 184)) * 128 : (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
+  const size_t stage = HALO ? (size_t)(BN + 184) * 128 : (size_t)NBUF * (BM + BN) * 128, epi = (size_t)(BM / WGM) * (BN + 4) * 4;
   size_t lds = stage > epi ? stage : epi;
   if (a.res_lds) lds += (size_t)BM * BN * sizeof(T);
   if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
@@ -634,18 +643,7 @@ static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
 // Tile choice: widest N tile the layer fills (MFMA-bound 3x3 convs); HBM-bound pointwise convs
 // prefer 128x64 (fewer registers -> more co-resident blocks -> more loads in flight: measured
 // 3-5 % faster on the bottleneck 1x1 layers); drop to BM=64 when the grid would not fill 256 CUs.
-void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN, bool pipe_ok) {
-  // MFMA-bound layers go to the deep-pipelined 256x256 kernel (one block per CU) when its rounds fill: at
-  // least two rounds over the 256 CUs and >= 80 % of the last one used (res4.conv2 at B=32: 525 tiles =
-  // 2.05 rounds -> 3 rounds at 68 %: measured 223 us vs 203 us for the 128x128 kernel).
-  static const int pipe_on = getenv("SYLPH_CONV_PIPE") ? atoi(getenv("SYLPH_CONV_PIPE")) : 0;  // off: the halo-tile mode of conv_igemm is faster end to end (1454 vs 1439 img/s)
-  const long ptiles = (long)((rows_total + 255) / 256) * (cout / 256);
-  const long prounds = (ptiles + 255) / 256;
-  if (pipe_on && pipe_ok && ntaps > 1 && cout % 256 == 0 &&
-      (pipe_on == 2 || (ptiles >= 512 && ptiles * 10 >= prounds * 256 * 8))) {
-    *BM = 256; *BN = 256;
-    return;
-  }
+void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
   int bn = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
   // (pointwise convs used to prefer 128x64 for occupancy; since the per-tile instruction diet 128x128 is equal or
   // better on every bottleneck 1x1: less LDS-DMA traffic per flop)
@@ -676,7 +674,7 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   a.res_lds = (res_lds_on && a.res_mode != 0 && BN == 64 && a.Cout % 64 == 0 && (a.res_ld & 7) == 0) ? 1 : 0;
   a.ss_padded_host = a.ss_padded;
   if (!ss_on || BN > 64) a.ss_padded = 0;  // the wide tiles are MFMA-bound and have no VGPRs to spare for the prefetch
-  if (BM == 256 && BN == 256) return conv_pipe_ok(dt, out_f32, a) ? launch_conv_pipe(a, s) : -8;
+  if (BM == 256 && BN == 256) return conv_hpipe_ok(dt, out_f32, a) ? launch_conv_hpipe(a, s) : -8;
   if (a.KH * a.KW > 31) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
   if (a.Cin % bk != 0) return -4;
@@ -684,9 +682,6 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   if (!a.zeros) return -5;
   if (dt == DT_BF16) {
     if (a.halo) {  // 3x3 s1 p1 with patch tiles (sylph_api.hip builds the matching tile table)
-      if (BM == 256 && BN == 128 && !out_f32 && g_nbuf == 1)  // 16 x 16 patches, 8 waves
-        return fast_ok(a, BN) ? launch_cfg<bf16_t, bf16_t, 256, 128, 4, 2, 1, true, true>(a, s)
-                              : launch_cfg<bf16_t, bf16_t, 256, 128, 4, 2, 1, false, true>(a, s);
       if (g_nbuf != 1 || BM != 128 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.stem || a.in2) return -9;
       if (BN == 32) {  // narrow prediction convs (bbox/ctrness, code-generator heads): fp32 or bf16 out
         return out_f32 ? launch_cfg<bf16_t, float, 128, 32, 4, 1, 1, false, true>(a, s)

@@ -109,6 +109,7 @@ struct sylph_ctx {
   bool has_backbone = false, has_head = false, has_codegen = false, has_roienc = false;
   // plans
   std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
+  std::map<const void*, void*> hp_weights;  // conv_hpipe.hip re-packed copies of 3x3 weights, keyed by the igemm-layout pointer
   Plan* cur = nullptr;
   void* zeros = nullptr;  // 256 B of zeros (conv out-of-image taps)
   // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
@@ -336,22 +337,66 @@ static int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geo
   return 0;
 }
 
-// 3x3 s1 p1 halo mode (conv_igemm.hip HALO): M tiles are 8 x 16 patches of one segment, tile.y = (row << 16) | col
-static int make_geom_patch(sylph_ctx* c, const std::vector<SegDesc>& segs, int PH, Geom* g) {
+// Patch shape of the halo-tile conv modes for an H x W map: ph x pw <= max_pos output positions whose (ph + 2) x (pw + 2)
+// input halo fits in halo_rows LDS rows of pitch pw + xpad, chosen to minimise the number of patches (= padded positions).
+// The fragment reads of the pad positions m in [ph * pw, max_pos) must stay inside the halo allocation too.
+// 800 x 1344 pyramid: 100 x 168 and 50 x 84 -> 10 x 12 (no ragged edge), 25 x 42 -> 9 x 14, 13 x 21 -> 13 x 7 / 7 x 11 -> 7 x 11;
+// per image 188 patches of 128 = 24 064 positions for 22 400 real ones (8 x 16 everywhere: 202 patches).
+static void pick_patch(int H, int W, int max_pos, int halo_rows, int xpad, int* ph_out, int* pw_out) {
+  long best_n = -1;
+  int bh = 8, bw = 16, best_halo = 0;
+  for (int w = 4; w <= 32; ++w) {
+    for (int h = 1; h * w <= max_pos; ++h) {
+      if ((h + 2) * (w + xpad) > halo_rows) continue;
+      if (((max_pos - 1) / w + 2) * (w + xpad) + (max_pos - 1) % w + 2 >= halo_rows) continue;
+      const long n = (long)((H + h - 1) / h) * ((W + w - 1) / w);
+      const int halo = (h + 2) * (w + 2);
+      const bool better = best_n < 0 || n < best_n || (n == best_n && (halo < best_halo || (halo == best_halo && w == 16)));
+      if (better) { best_n = n; bh = h; bw = w; best_halo = halo; }
+    }
+  }
+  *ph_out = bh; *pw_out = bw;
+}
+
+static void set_patch(SegDesc* s, int ph, int pw, int xpad) {
+  s->ph = ph; s->pw = pw; s->hpitch = pw + xpad;
+  s->inv_pw = (65536u + pw - 1) / pw;
+  s->inv_hw2 = (65536u + s->hpitch - 1) / s->hpitch;
+}
+
+// 3x3 s1 p1 halo modes: M tiles are ph x pw patches of one segment, tile.y = (row << 16) | col.  `pair`: the tile list is
+// padded to an even length with an empty patch (conv_halo_pipe.hip works on two patches per block).
+static int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g) {
   std::vector<int2> tiles;
+  static const int fixed = getenv("SYLPH_CONV_PATCH_8X16") ? atoi(getenv("SYLPH_CONV_PATCH_8X16")) : 0;  // A/B knob: the round-1 geometry
   for (size_t s = 0; s < segs.size(); ++s) {
+    int ph, pw;
+    if (fixed) { ph = max_pos / 16; pw = 16; }
+    else pick_patch(segs[s].out_H, segs[s].out_W, max_pos, halo_rows, xpad, &ph, &pw);
+    set_patch(&segs[s], ph, pw, xpad);
     const int t0 = (int)tiles.size();
-    for (int y = 0; y < segs[s].out_H; y += PH)
-      for (int x = 0; x < segs[s].out_W; x += 16) tiles.push_back(make_int2((int)s, (y << 16) | x));
+    for (int y = 0; y < segs[s].out_H; y += ph)
+      for (int x = 0; x < segs[s].out_W; x += pw) tiles.push_back(make_int2((int)s, (y << 16) | x));
     g->seg_tiles.push_back(make_int2(t0, (int)tiles.size() - t0));
   }
+  g->n_mtiles = (int)tiles.size();
+  if (pair && (tiles.size() & 1)) tiles.push_back(make_int2(0, 0x7fff << 16));  // origin below every map: nothing loaded, nothing stored
   void *ds = nullptr, *dtl = nullptr;
   RET(upload(c, &ds, segs.data(), segs.size() * sizeof(SegDesc)));
   RET(upload(c, &dtl, tiles.data(), tiles.size() * sizeof(int2)));
   g->segs = (const SegDesc*)ds;
   g->tiles = (const int2*)dtl;
-  g->n_mtiles = (int)tiles.size();
   return 0;
+}
+
+static long patch_count(const std::vector<SegDesc>& segs, int max_pos, int halo_rows, int xpad) {
+  long n = 0;
+  for (auto& sg : segs) {
+    int ph, pw;
+    pick_patch(sg.out_H, sg.out_W, max_pos, halo_rows, xpad, &ph, &pw);
+    n += (long)((sg.out_H + ph - 1) / ph) * ((sg.out_W + pw - 1) / pw);
+  }
+  return n;
 }
 
 // launch the conv kernel, optionally bracketed by HIP events on the same stream
@@ -412,31 +457,49 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   for (auto& s : segs) rows += (long)s.out_H * s.out_W;
   int BM, BN;
   const int cout_l = o.cout_override >= 0 ? o.cout_override : L.Cout;
-  const bool pipe_ok = c->dt == DT_BF16 && !o.out_f32 && !o.stem && !o.in2 && !o.res && o.res_mode == 0 && o.mul_nch == 0 &&
-                       o.cout_override < 0 && (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0;
-  conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN, pipe_ok);
+  conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN);
   if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
-  // 3x3 stride-1 convs on 128-row tiles: halo mode (input patch staged once per channel slice, 9 taps read it)
+  const bool k3s1 = L.KH == 3 && L.KW == 3 && o.stride == 1 && o.pad == 1 && !o.stem && !o.in2;
+  // MFMA-bound 3x3 stride-1 layers with Cout % 256 == 0 (FCOS towers, FPN outputs, res4/res5 conv2): the deep-pipelined
+  // halo kernel (conv_hpipe.hip, one 256 x 256 tile = two patches per CU) when its rounds fill the chip: at least two
+  // rounds over the 256 CUs and >= 80 % of the last one used.
+  static const int hp_on = getenv("SYLPH_CONV_HPIPE") ? atoi(getenv("SYLPH_CONV_HPIPE")) : 1;
+  bool hpipe = false;
+  if (hp_on && k3s1 && c->dt == DT_BF16 && !o.out_f32 && !o.res && o.res_mode == 0 && o.mul_nch == 0 && o.cout_override < 0 &&
+      (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0 && L.Cout % 256 == 0 && L.Cout == L.Cout_pad) {
+    const long blocks = (patch_count(segs, 128, 256, 4) + 1) / 2 * (L.Cout / 256), rounds = (blocks + 255) / 256;
+    hpipe = hp_on == 2 || (blocks >= 512 && blocks * 10 >= rounds * 256 * 8);
+  }
+  if (hpipe) { BM = 256; BN = 256; }
+  // other 3x3 stride-1 convs on 128-row tiles: halo mode (input patch staged once per channel slice, 9 taps read it)
   static const int halo_on = getenv("SYLPH_CONV_HALO") ? atoi(getenv("SYLPH_CONV_HALO")) : 1;
-  bool halo = halo_on && c->dt == DT_BF16 && BM == 128 && (BN == 32 || (!o.out_f32 && (BN == 128 || BN == 64))) && L.KH == 3 && L.KW == 3 &&
-              o.stride == 1 && o.pad == 1 && !o.stem && !o.in2 && L.Cin % 64 == 0;
-  static const int halo_bm = getenv("SYLPH_CONV_HALO_BM") ? atoi(getenv("SYLPH_CONV_HALO_BM")) : 128;
-  if (halo && halo_bm == 256 && BN == 128 && !o.out_f32 && rows >= 256 * 1024) BM = 256;
-  if (halo) {  // patches must not waste much of the launch on ragged edges (tiny pyramid levels are cheap anyway)
-    long patch_rows = 0;
-    const int PH = BM / 16;
-    for (auto& sg : segs) patch_rows += (long)((sg.out_H + PH - 1) / PH) * ((sg.out_W + 15) / 16) * BM;
-    if (halo_on != 2 && patch_rows * 10 > rows * 15) halo = false;  // res5 (25x42 maps: 46 % waste) still wins: 247 -> 198 us at B=32
+  bool halo = !hpipe && halo_on && c->dt == DT_BF16 && BM == 128 && (BN == 32 || (!o.out_f32 && (BN == 128 || BN == 64))) && k3s1 &&
+              L.Cin % 64 == 0;
+  if (halo) {  // patches must not waste much of the launch on ragged edges (tiny maps are cheap anyway)
+    const long patch_rows = patch_count(segs, 128, 184, 2) * 128;
+    if (halo_on != 2 && patch_rows * 10 > rows * 15) halo = false;
   }
   Geom g;
-  if (halo) RET(make_geom_patch(c, segs, BM / 16, &g));
+  if (hpipe) RET(make_geom_patch(c, segs, 128, 256, 4, true, &g));
+  else if (halo) RET(make_geom_patch(c, segs, 128, 184, 2, false, &g));
   else RET(make_geom(c, segs, BM, &g));
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.halo = halo ? 1 : 0;
+  a.halo = hpipe ? 2 : (halo ? 1 : 0);
   a.in = in; a.wt = L.w; a.out = out; a.res = o.res;
+  if (hpipe) {  // stage-image weight layout of conv_hpipe.hip, packed once per layer
+    auto it = c->hp_weights.find(L.w);
+    if (it == c->hp_weights.end()) {
+      void* wp = nullptr;
+      RET(c->dalloc(&wp, (size_t)L.Cout * 9 * L.Cin * 2));
+      KCHK(launch_hpipe_pack_weights(L.w, wp, L.Cout, L.Cin, c->stream), "hpipe_pack_weights");
+      HIPCHK(hipStreamSynchronize(c->stream));
+      it = c->hp_weights.emplace(L.w, wp).first;
+    }
+    a.wt = it->second;
+  }
   a.scale = L.scale; a.shift = L.shift; a.zeros = c->zeros;
-  a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;
+  a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = hpipe ? (g.n_mtiles + 1) / 2 : g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;
   a.Cin = L.Cin; a.Cout = o.cout_override >= 0 ? o.cout_override : L.Cout;
   a.KH = L.KH; a.KW = L.KW; a.stride = o.stride; a.pad = o.pad;
   a.in_ld = in_ld; a.out_ld = out_ld; a.res_ld = o.res_ld;
@@ -450,7 +513,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   }
   if (o.want_gn) {
     if (L.Cout != 256 && L.Cout != 512) return fail("fused GroupNorm statistics need Cout == 256 or 512");
-    RET(c->dalloc((void**)&a.gn_partial, (size_t)g.n_mtiles * (L.Cout / 8) * 3 * sizeof(float)));
+    RET(c->dalloc((void**)&a.gn_partial, (size_t)(g.n_mtiles + 1) * (L.Cout / 8) * 3 * sizeof(float)));  // +1: the pad patch of an odd pair list
   }
   if (geom_out) { *geom_out = g; geom_out->gn_partial = a.gn_partial; }
   const DType dt = c->dt;

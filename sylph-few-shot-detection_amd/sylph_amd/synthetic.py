@@ -1,6 +1,6 @@
-"""Oracle helper: seeded synthetic weights in the reference's checkpoint key layout,
-synthetic query/support inputs.  TEST INFRASTRUCTURE (also used by bench.py to build inputs;
-it performs no model arithmetic).
+"""Seeded synthetic weights in the reference's checkpoint key layout and synthetic query / support
+inputs: what bench.py, the smoke test and the parity tests feed to BOTH the HIP path and the CPU oracle.
+Pure data generation: no model arithmetic, no dependency on oracle/.
 
 Key layout (state_dict of sylph MetaOneStageDetector, captured from the reference modules):
   backbone.bottom_up.stem.conv1.{weight,norm.*}, backbone.bottom_up.res{2..5}.{i}.{shortcut,conv1,
@@ -17,7 +17,7 @@ from typing import Dict, List, Tuple
 
 import torch
 
-from .backbone import STAGE_BLOCKS
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # detectron2 ResNet depths
 
 
 def _conv(g, cout, cin, k, std=None):

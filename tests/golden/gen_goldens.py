@@ -5,7 +5,7 @@
 
 Writes tests/golden/*.npz (inputs + expected outputs; data only).  The reference never travels:
 the GPU box replays these fixtures against the oracle and the HIP path.
-Weights are NOT stored (too large); they are regenerated from oracle.weights seeds and guarded by
+Weights are NOT stored (too large); they are regenerated from sylph_amd.synthetic seeds and guarded by
 a checksum stored in each fixture.
 """
 import os
@@ -24,7 +24,7 @@ import ref_shim  # noqa: E402
 
 ref_shim.install()
 
-from oracle import weights as W  # noqa: E402
+from sylph_amd import synthetic as W  # noqa: E402
 from sylph_amd.config import get_default_cfg  # noqa: E402
 
 
@@ -174,6 +174,47 @@ def gen_codegen():
     np.savez_compressed(os.path.join(HERE, "g3_codegen.npz"), **out)
 
 
+def gen_codegen_s10():
+    """BASELINE config C3 support path: 10 shots of one class (mean over shots, code_generator.py:766-829), COCO and
+    LVIS (BIAS_L2_NORM) settings, boxes on levels 3..6.  Separate file so that g3_codegen.npz stays bit-stable."""
+    from sylph.modeling.code_generator.code_generator import CodeGenerator
+    from ref_shim import Boxes, Instances
+    out = {}
+    sd = W.codegen_state_dict(seed=2)
+    out["weights_checksum"] = checksum(sd, "code_generator")
+    H, Wd, S = 128, 160, 10
+    feats = feature_pyramid(S, H, Wd, seed=110)
+    boxes = W.synthetic_boxes(S, H, Wd, seed=210)
+    boxes[0] = torch.tensor([2.0, 3.0, 30.0, 28.0])       # level 3
+    boxes[1] = torch.tensor([0.0, 0.0, 159.0, 127.0])     # whole image -> level 3 (sqrt(area) < 224)
+    boxes[2] = torch.tensor([10.5, 20.25, 150.75, 120.0])
+    boxes[3] = torch.tensor([100.0, 90.0, 160.0, 128.0])  # touches the bottom-right corner
+    for l, f in enumerate(feats):
+        out[f"s{S}_feat{l}_q8"] = q8(f)
+    out[f"s{S}_boxes"] = boxes.numpy()
+    for lvis in (False, True):
+        cfg = make_cfg(lvis)
+        gen = CodeGenerator(cfg, 256, 5, cfg.MODEL.FCOS.FPN_STRIDES).eval()
+        load_prefixed(gen, sd, "code_generator")
+        insts = []
+        for i in range(S):
+            it = Instances((H, Wd))
+            it.gt_boxes = Boxes(boxes[i:i + 1])
+            it.gt_classes = torch.tensor([3])
+            insts.append(it)
+        with torch.no_grad():
+            code = gen(feats, insts)
+            tag = f"{'lvis' if lvis else 'coco'}_s{S}"
+            out[f"{tag}_cls_conv"] = code["cls_conv"].numpy()
+            out[f"{tag}_cls_bias"] = code["cls_bias"].numpy()
+            rec = [{"support_set_target": torch.tensor(0), "class_name": "c10", "class_code": {k: v.clone() for k, v in code.items()}}]
+            normed = gen(None, None, cls_norm=True, class_codes=rec)
+            out[f"{tag}_norm_cls_conv"] = normed[0]["class_code"]["cls_conv"].numpy()
+            out[f"{tag}_norm_cls_bias"] = normed[0]["class_code"]["cls_bias"].numpy()
+        print("codegen", tag, code["cls_conv"].flatten()[:3], code["cls_bias"].flatten())
+    np.savez_compressed(os.path.join(HERE, "g3b_codegen_s10.npz"), **out)
+
+
 def gen_reduce_condblock():
     from sylph.modeling.code_generator.utils import reduce_class_code
     from sylph.modeling.meta_fcos.head_utils import CondConvBlock
@@ -256,8 +297,8 @@ def gen_roi_encoder():
 if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
-    gen_head_decode()
-    gen_codegen()
-    gen_reduce_condblock()
-    gen_roi_encoder()
+    only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
+    for fn in (gen_head_decode, gen_codegen, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+        if not only or fn.__name__ in only:
+            fn()
     print("done")

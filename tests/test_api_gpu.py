@@ -17,7 +17,7 @@ def _cfg():
 
 @pytest.fixture(scope="module")
 def sd():
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     return W.synthetic_state_dict(0, depth=50)
 
 

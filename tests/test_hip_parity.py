@@ -110,7 +110,7 @@ def g3(golden_dir):
 
 @pytest.fixture(scope="module")
 def head_engine():
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg())
     eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
     return eng
@@ -133,7 +133,7 @@ def test_head_matches_reference_golden(g1, head_engine, tag):
 @pytest.mark.parametrize("tag,thr", [("n1_t50", 0.05), ("n5_t50", 0.05), ("n20_t50", 0.05), ("n20_t11", 0.011)])
 def test_decode_matches_reference_golden(g1, tag, thr):
     """boxes/scores within 1e-3 and identical kept (level, location, class) triples."""
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": thr}))
     eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
     sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
@@ -159,7 +159,7 @@ def test_decode_matches_reference_golden(g1, tag, thr):
 @pytest.mark.parametrize("lvis", [False, True])
 @pytest.mark.parametrize("S", [1, 2, 5])
 def test_codegen_matches_reference_golden(g3, lvis, S):
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg(lvis))
     eng.load_state_dict(W.codegen_state_dict(seed=2))
     eng.import_pyramid(_feats(g3, f"s{S}_feat"), (192, 256))
@@ -171,7 +171,7 @@ def test_codegen_matches_reference_golden(g3, lvis, S):
 
 @pytest.mark.parametrize("tagc", ["coco", "lvis"])
 def test_normalize_matches_reference_golden(g3, tagc):
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg(tagc == "lvis"))
     eng.load_state_dict(W.codegen_state_dict(seed=2))
     codes = torch.stack([torch.cat([torch.from_numpy(g3[f"{tagc}_s{S}_cls_conv"]).reshape(-1),
@@ -185,12 +185,13 @@ def test_normalize_matches_reference_golden(g3, tagc):
 # --------------------------------------------------------------------------------- oracle, end to end
 @pytest.fixture(scope="module")
 def full_sd():
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     return W.synthetic_state_dict(0, depth=50)
 
 
 def test_backbone_fpn_matches_oracle_f32(full_sd):
-    from oracle import backbone as OB, weights as W
+    from oracle import backbone as OB
+    from sylph_amd import synthetic as W
     imgs = W.synthetic_images(2, 120, 150, seed=5)
     imgs[1] = imgs[1][:, :97, :131].contiguous()
     eng = _engine("f32", _cfg())
@@ -208,7 +209,8 @@ def test_backbone_fpn_matches_oracle_f32(full_sd):
 
 
 def test_backbone_fpn_bf16_close_to_oracle(full_sd):
-    from oracle import backbone as OB, weights as W
+    from oracle import backbone as OB
+    from sylph_amd import synthetic as W
     imgs = W.synthetic_images(1, 128, 160, seed=6)
     eng = _engine("bf16", _cfg())
     eng.load_state_dict(full_sd)
@@ -224,7 +226,8 @@ def test_backbone_fpn_bf16_close_to_oracle(full_sd):
 
 
 def _episode_codes(eng, sd, n_cls, shots, h, w, oracle_too=True):
-    from oracle import weights as W, episode as E, codegen as CG
+    from oracle import episode as E, codegen as CG
+    from sylph_amd import synthetic as W
     codes_gpu, codes_ref = [], []
     for c in range(n_cls):
         sup = W.synthetic_images(shots, h, w, seed=50 + c)
@@ -246,7 +249,8 @@ def _episode_codes(eng, sd, n_cls, shots, h, w, oracle_too=True):
 def test_full_episode_matches_oracle_f32(full_sd):
     """C1-shaped episode (5-way 1-shot, 2 queries) at small size: codes, boxes, scores <= 1e-3 and the
     same kept (level, location, class) candidates."""
-    from oracle import weights as W, episode as E
+    from oracle import episode as E
+    from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg())
     eng.load_state_dict(full_sd)
     g, ref = _episode_codes(eng, full_sd, 5, 1, 128, 160)
@@ -284,7 +288,7 @@ def _cand_ordinals(inst, H, W, N):
 
 def test_full_size_properties_bf16(full_sd):
     """BASELINE config C2 shape (800x1333 -> 800x1344, 5-way): size-independent properties."""
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("bf16", _cfg())
     eng.load_state_dict(full_sd)
     q = W.synthetic_images(2, 800, 1333, seed=3)
@@ -332,7 +336,7 @@ def _roienc_cfg():
 
 @pytest.mark.parametrize("S", [2, 5])
 def test_roi_encoder_matches_reference_golden(golden_dir, S):
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     g = np.load(os.path.join(golden_dir, "g7_roi_encoder.npz"))
     eng = _engine("f32", _roienc_cfg())
     eng.load_state_dict(W.roi_encoder_state_dict(seed=4))
@@ -344,7 +348,7 @@ def test_roi_encoder_matches_reference_golden(golden_dir, S):
 
 
 def test_roi_encoder_bf16_close(golden_dir):
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     g = np.load(os.path.join(golden_dir, "g7_roi_encoder.npz"))
     eng = _engine("bf16", _roienc_cfg())
     eng.load_state_dict(W.roi_encoder_state_dict(seed=4))
@@ -357,7 +361,8 @@ def test_roi_encoder_bf16_close(golden_dir):
 # --------------------------------------------------------------------------------- C3 / C4 shaped cases
 def test_r101_backbone_matches_oracle_f32():
     """BASELINE config C4 backbone (MODEL.RESNETS.DEPTH 101) at small size."""
-    from oracle import backbone as OB, weights as W
+    from oracle import backbone as OB
+    from sylph_amd import synthetic as W
     sd = W.backbone_state_dict(0, depth=101)
     imgs = W.synthetic_images(1, 96, 128, seed=8)
     eng = _engine("f32", _cfg(**{"MODEL.RESNETS.DEPTH": 101}))
@@ -376,7 +381,8 @@ def test_r101_backbone_matches_oracle_f32():
 def test_many_class_decode_topk_matches_oracle(g1, N, thr, post):
     """Many-way decode (LVIS-sized N): > PRE_NMS_TOPK candidates on a level -> exact radix top-k, NMS, keep
     POST_NMS_TOPK(+ties).  Decode is checked on the SAME head outputs (exported), so every difference is decode."""
-    from oracle import decode as OD, weights as W
+    from oracle import decode as OD
+    from sylph_amd import synthetic as W
     cfg = _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": thr, "MODEL.FCOS.POST_NMS_TOPK_TEST": post})
     eng = _engine("f32", cfg)
     eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
@@ -399,7 +405,7 @@ def test_many_class_decode_topk_matches_oracle(g1, N, thr, post):
 
 
 def test_candidate_overflow_fails_loudly(g1):
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": 0.011}), cand_cap=64)
     eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
     eng.import_pyramid(_feats(g1), (128, 160))
@@ -411,7 +417,7 @@ def test_candidate_overflow_fails_loudly(g1):
 
 def test_c3_shape_runs_bf16(full_sd):
     """BASELINE config C3 shape: 20-way, batch 16 queries (smaller images to keep the test short)."""
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("bf16", _cfg())
     eng.load_state_dict(full_sd)
     q = W.synthetic_images(16, 256, 320, seed=12)
@@ -427,7 +433,7 @@ def test_c3_shape_runs_bf16(full_sd):
 def test_c4_shape_runs_bf16_full_size():
     """BASELINE config C4 at full query size: R-101, 866 classes (LVIS), 300 detections, batch 2 of 800x1333.
     Exercises the production kernel selection (halo tiles, stem kernel, radix top-k over 866-wide score rows)."""
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     cfg = _cfg(**{"MODEL.RESNETS.DEPTH": 101, "MODEL.FCOS.POST_NMS_TOPK_TEST": 300})
     eng = _engine("bf16", cfg)
     eng.load_state_dict(W.synthetic_state_dict(0, depth=101))
@@ -451,7 +457,7 @@ def test_c4_shape_runs_bf16_full_size():
 def test_c5_query_shape_runs_bf16():
     """BASELINE config C5 query geometry: 800x1200 queries (padded to 800x1216: level widths 152/76/38/19/10, not
     multiples of the 16-wide halo patches), 337 classes."""
-    from oracle import weights as W
+    from sylph_amd import synthetic as W
     eng = _engine("bf16", _cfg())
     eng.load_state_dict(W.synthetic_state_dict(0, depth=50))
     q = W.synthetic_images(3, 800, 1200, seed=31)

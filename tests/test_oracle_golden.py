@@ -10,7 +10,7 @@ from oracle import codegen as CG
 from oracle import decode as D
 from oracle import episode as E
 from oracle import head as H
-from oracle import weights as W
+from sylph_amd import synthetic as W
 
 TOL = 2e-5
 

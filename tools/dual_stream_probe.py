@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sylph-few-shot-detection_amd"))
 from bench import make_cfg, dev_images
-from oracle import weights as W
+from sylph_amd import synthetic as W
 from sylph_amd.engine import Engine
 
 dev = torch.device("cuda", 0)

@@ -13,6 +13,9 @@ LAYERS = {
     "res2.conv1": (200, 336, 256, 64, 1, 1, 0, 0, 0),
     "res3.conv3": (100, 168, 128, 512, 1, 1, 0, 1, 0),
     "tower": (100, 168, 256, 256, 3, 1, 1, 0, 1),
+    "fpn.out3": (100, 168, 256, 256, 3, 1, 1, 0, 0),
+    "res4.conv2": (50, 84, 256, 256, 3, 1, 1, 0, 0),
+    "res3.conv2": (100, 168, 128, 128, 3, 1, 1, 0, 0),
 }
 name = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
