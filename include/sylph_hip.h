@@ -54,7 +54,7 @@ typedef struct sylph_config {
   int cg_conv_l2_norm;     /* CODE_GENERATOR.CONV_L2_NORM */
   int cg_use_weight_scale; /* CODE_GENERATOR.USE_WEIGHT_SCALE */
   float prior_prob;        /* MODEL.FCOS.PRIOR_PROB */
-  int cand_cap;            /* per (image, level) candidate capacity of the decode scan (0 = default: 1/8 of the largest level's location x class scores, at least 65536) */
+  int cand_cap;            /* per (image, level) candidate capacity of the decode scan (0 = default: every location x class score of the largest level up to 262144 slots, else 1/8 of them, at most 4 M) */
   /* ROIEncoder variant (sylph/runner/default_configs.py:149-167; LVIS ROI-Encoder yaml) */
   int cg_type;             /* CODE_GENERATOR.NAME: 0 "CodeGenerator", 1 "ROIEncoder" */
   int tok_num_conv;        /* TOKENIZER.NUM_CONV (conv3x3 + GN + ReLU, CONV_DIM 256, NORM "GN") */
@@ -105,6 +105,13 @@ int sylph_fcos_head(sylph_ctx* ctx, const float* cls_conv_dev, const float* cls_
 int sylph_export_head(sylph_ctx* ctx, int level, float* logits_nchw_dev, float* reg_nchw_dev, float* ctr_nchw_dev,
                       float* iou_nchw_dev);
 
+/* Boundary/test entry, inverse of sylph_export_head: load level `level` of the head outputs of the current batch from
+ * fp32 NCHW device tensors (logits (B,N,h,w), reg (B,4,h,w) already relu(scale*bbox_pred), ctr (B,1,h,w), iou (B,1,h,w);
+ * NULL leaves that plane untouched), so that sylph_decode_nms can be driven with known head outputs (the
+ * predict_proposals / ml_nms / detector_postprocess known-answer cases, fcos_outputs.py:904-1028). */
+int sylph_import_head(sylph_ctx* ctx, int N, int level, const float* logits_nchw_dev, const float* reg_nchw_dev,
+                      const float* ctr_nchw_dev, const float* iou_nchw_dev);
+
 /* FCOSOutputs.predict_proposals + select_over_all_levels + detector_postprocess
  * (sylph/modeling/meta_fcos/fcos_outputs.py:743-812,904-1028; meta_one_stage_detector.py:288-296).
  * out_heights/out_widths (host, may be NULL = image size): the "height"/"width" of each input dict.
@@ -123,6 +130,11 @@ int sylph_decode_nms(sylph_ctx* ctx, const int* out_heights, const int* out_widt
  * normalisation step exists for this variant). */
 int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
 
+/* Boundary/test entry: the ROIPooler call of the code generator alone (code_generator.py:341-348,928-930: box ->
+ * level assignment -> ROIAlignV2 aligned, adaptive sampling, 7x7).  The current batch holds S images, boxes_dev (S,4)
+ * one XYXY box per image; out_nchw_dev (S,256,7,7) fp32. */
+int sylph_roi_align(sylph_ctx* ctx, const float* boxes_dev, float* out_nchw_dev);
+
 /* CodeGeneratorHead.forward_normalize_code (code_generator.py:832-897): codes_dev (n,257) in place. */
 int sylph_normalize_codes(sylph_ctx* ctx, float* codes_dev, int n);
 
@@ -134,6 +146,13 @@ int sylph_conv2d(sylph_ctx* ctx, const float* x_nchw_dev, int B, int C, int H, i
                  const float* residual_nchw_dev, float* y_nchw_dev);
 int sylph_group_norm(sylph_ctx* ctx, const float* x_nchw_dev, int B, int H, int W, const float* gamma_host,
                      const float* beta_host, int relu, float* y_nchw_dev);
+
+/* Kernel parity test entry for the dedicated ResNet stem kernels (bf16 contexts only): x (B,3,H,W) fp32 NCHW device,
+ * already normalised; w_host (64,3,7,7), scale/shift host (64) = folded FrozenBN.  stem_out (B,64,H/2,W/2) =
+ * relu(bn(conv7x7 s2 p3)), pool_out (B,64,H/4,W/4) = maxpool 3x3 s2 p1 of it; either may be NULL.
+ * (detectron2 BasicStem; call site meta_one_stage_detector.py:181,273.) */
+int sylph_stem_maxpool(sylph_ctx* ctx, const float* x_nchw_dev, int B, int H, int W, const float* w_host,
+                       const float* scale_host, const float* shift_host, float* stem_out_nchw_dev, float* pool_out_nchw_dev);
 
 /* Bytes of device memory currently held by the context (weights + workspace). */
 int64_t sylph_device_bytes(sylph_ctx* ctx);

@@ -123,8 +123,19 @@ struct sylph_ctx {
     hipError_t e = hipMalloc(p, n);
     if (e != hipSuccess) return fail(std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
     allocs.push_back(*p);
+    alloc_bytes[*p] = n;
     bytes += (int64_t)n;
     return 0;
+  }
+  std::map<void*, size_t> alloc_bytes;
+  void dfree(void* p) {  // release one dalloc'ed buffer (the stream may still use it: drain first)
+    if (!p) return;
+    (void)hipStreamSynchronize(stream);
+    for (size_t i = 0; i < allocs.size(); ++i)
+      if (allocs[i] == p) { allocs[i] = allocs.back(); allocs.pop_back(); break; }
+    auto it = alloc_bytes.find(p);
+    if (it != alloc_bytes.end()) { bytes -= (int64_t)it->second; alloc_bytes.erase(it); }
+    (void)hipFree(p);
   }
   size_t esz() const { return dt == DT_BF16 ? 2 : 4; }
 };
@@ -835,13 +846,15 @@ static int build_head(sylph_ctx* c, Plan* P) {
 }
 
 // Per-(image, level) capacity of the decode candidate buffers.  The reference has no cap (boolean-mask indexing,
-// fcos_outputs.py:960-990); here the scan compacts into a fixed buffer and overflow is reported, so the default
-// leaves room for 1/8 of all (location, class) scores of the largest level passing the threshold: 65 536 for 5-way,
-// 1.8 M for LVIS 866-way (HBM is plentiful: 8 bytes per slot).
+// fcos_outputs.py:960-990); here the scan compacts into a fixed buffer and overflow is reported.  Up to 262 144 slots the
+// buffer holds EVERY (location, class) score of the largest level (5-way: 84 000, 20-way: 262 144 of 336 000), i.e. it cannot
+// overflow for few-shot class counts; many-way episodes get 1/8 of the scores (LVIS 866-way: 1.8 M), at most 4 M
+// (HBM is plentiful: 8 bytes per slot).
 static int want_cand_cap(const sylph_ctx* c, const Plan* P) {
   if (c->cfg.cand_cap > 0) return c->cfg.cand_cap;
-  long w = (long)P->hl[0] * P->wl[0] * (long)(P->ncls > 0 ? P->ncls : 1) / 8;
-  if (w < 65536) w = 65536;
+  const long all = (long)P->hl[0] * P->wl[0] * (long)(P->ncls > 0 ? P->ncls : 1);
+  long w = all <= 262144 ? all : (all / 8 > 262144 ? all / 8 : 262144);
+  if (w < 4096) w = 4096;
   if (w > (1L << 22)) w = 1L << 22;
   return (int)w;
 }
@@ -1453,6 +1466,69 @@ int sylph_export_pyramid(sylph_ctx* c, int level, float* out) {
   return 0;
 }
 
+// logits / packed-code buffers of the current batch for N classes (grown on demand; the previous buffers are released)
+static int ensure_logits(sylph_ctx* c, Plan* P, int N) {
+  const size_t rows = (size_t)P->B * P->Ltot;
+  const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
+  const int Npad = (N + bn - 1) / bn * bn;
+  if (Npad > P->logits_cap_ld) {
+    if (P->logits) c->dfree(P->logits);
+    P->logits = nullptr; P->logits_cap_ld = 0;
+    RET(c->dalloc((void**)&P->logits, rows * Npad * sizeof(float)));
+    P->logits_cap_ld = Npad;
+  }
+  if (Npad > P->code_w_cap) {
+    if (P->code_w) c->dfree(P->code_w);
+    P->code_w = nullptr; P->code_w_cap = 0;
+    RET(c->dalloc(&P->code_w, (size_t)Npad * 256 * c->esz()));
+    P->code_w_cap = Npad;
+  }
+  P->logits_ld = Npad;
+  P->ncls = N;
+  return 0;
+}
+
+int sylph_import_head(sylph_ctx* c, int N, int level, const float* logits, const float* reg, const float* ctr, const float* iou) {
+  Plan* P = c->cur;
+  if (!P) return fail("no current batch");
+  if (N <= 0) return fail("class_code is empty");
+  if (level < 0 || level >= c->cfg.nlevels) return fail("bad level");
+  RET(build_head(c, P));
+  if (!P->logits || N != P->ncls) RET(ensure_logits(c, P, N));
+  const int hw = P->hl[level] * P->wl[level];
+  for (int b = 0; b < P->B; ++b) {
+    const int row0 = b * P->Ltot + P->off[level];
+    if (logits) KCHK(launch_import_nchw(DT_F32, logits + (size_t)b * N * hw, P->logits, N, hw, row0, P->logits_ld, c->stream), "import logits");
+    if (reg) KCHK(launch_import_nchw(DT_F32, reg + (size_t)b * 4 * hw, P->pred, 4, hw, row0, 8, c->stream), "import reg");
+    if (ctr) KCHK(launch_import_nchw(DT_F32, ctr + (size_t)b * hw, P->pred + 4, 1, hw, row0, 8, c->stream), "import ctr");
+    if (iou) KCHK(launch_import_nchw(DT_F32, iou + (size_t)b * hw, P->pred + 5, 1, hw, row0, 8, c->stream), "import iou");
+  }
+  return 0;
+}
+
+int sylph_roi_align(sylph_ctx* c, const float* boxes, float* out) {
+  Plan* P = c->cur;
+  if (!P || !P->F) return fail("no current batch");
+  if (!boxes || !out) return fail("NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  const int S = P->B, L = c->cfg.nlevels;
+  std::vector<LevelDesc> lv;
+  for (int b = 0; b < S; ++b)
+    for (int l = 0; l < L; ++l)
+      lv.push_back(LevelDesc{b * P->Ltot + P->off[l], P->hl[l], P->wl[l], 1.0f / (float)c->cfg.strides[l]});
+  sylph_ctx tmp;  // scratch allocations freed on return
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
+  LevelDesc* lvd = nullptr;
+  void* roi = nullptr;
+  RET(upload(&tmp, (void**)&lvd, lv.data(), lv.size() * sizeof(LevelDesc)));
+  RET(tmp.dalloc(&roi, (size_t)S * 49 * 256 * c->esz()));
+  KCHK(launch_roi_align(c->dt, P->F, 256, lvd, L, boxes, S, 7, roi, c->stream), "roi_align");
+  for (int s = 0; s < S; ++s)
+    KCHK(launch_export_nchw(c->dt, roi, out + (size_t)s * 256 * 49, 256, 49, s * 49, 256, c->stream), "export roi");
+  return 0;
+}
+
 int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, int N) {
   Plan* P = c->cur;
   if (!P) return fail("no current batch");
@@ -1462,16 +1538,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   const size_t rows = (size_t)P->B * P->Ltot;
   const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
   const int Npad = (N + bn - 1) / bn * bn;
-  if (Npad > P->logits_cap_ld) {
-    RET(c->dalloc((void**)&P->logits, rows * Npad * sizeof(float)));
-    P->logits_cap_ld = Npad;
-  }
-  if (Npad > P->code_w_cap) {
-    RET(c->dalloc(&P->code_w, (size_t)Npad * 256 * c->esz()));
-    P->code_w_cap = Npad;
-  }
-  P->logits_ld = Npad;
-  P->ncls = N;
+  RET(ensure_logits(c, P, N));
   RET(run_ops(c, P->head_ops, "fcos_head"));
   KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, c->stream), "pack_codes");
   ConvArgs a;
@@ -1516,6 +1583,8 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   if (want_cand_cap(c, P) > P->cand_cap) {  // more classes than when the plan was built: grow the candidate buffers
     const int nseg = P->B * c->cfg.nlevels;
     P->cand_cap = want_cand_cap(c, P);
+    c->dfree(P->dbuf.cand_key); c->dfree(P->dbuf.cand_idx);
+    P->dbuf.cand_key = nullptr; P->dbuf.cand_idx = nullptr;
     RET(c->dalloc((void**)&P->dbuf.cand_key, (size_t)nseg * P->cand_cap * 4));
     RET(c->dalloc((void**)&P->dbuf.cand_idx, (size_t)nseg * P->cand_cap * 4));
   }
@@ -1633,6 +1702,43 @@ int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const fl
   KCHK(launch_groupnorm(c->dt, buf, rsd, B, HW, 256, ga, be, 1e-5f, relu, partial, stats, c->stream), "group_norm");
   for (int b = 0; b < B; ++b)
     KCHK(launch_export_nchw(c->dt, buf, y + (size_t)b * 256 * HW, 256, HW, b * HW, 256, c->stream), "export");
+  return 0;
+}
+
+int sylph_stem_maxpool(sylph_ctx* c, const float* x, int B, int H, int W, const float* w_host, const float* scale_host,
+                       const float* shift_host, float* stem_out, float* pool_out) {
+  if (c->dt != DT_BF16) return fail("sylph_stem_maxpool: the dedicated stem kernels exist in bf16 mode only");
+  HIPCHK(hipSetDevice(c->device));
+  sylph_ctx tmp;  // scratch allocations freed on return
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
+  const int H2 = (H - 1) / 2 + 1, W2 = (W - 1) / 2 + 1, H4 = (H2 - 1) / 2 + 1, W4 = (W2 - 1) / 2 + 1;
+  std::vector<bf16_t> wp((size_t)64 * 224);  // [n][kh][8 px][4 ch], kernel column 7 / channel 3 zero (as sylph_finalize_weights)
+  for (int n = 0; n < 64; ++n)
+    for (int kh = 0; kh < 7; ++kh)
+      for (int px = 0; px < 8; ++px)
+        for (int ch = 0; ch < 4; ++ch)
+          wp[(size_t)n * 224 + kh * 32 + px * 4 + ch] = (bf16_t)((px < 7 && ch < 3) ? w_host[((n * 3 + ch) * 7 + kh) * 7 + px] : 0.f);
+  void *wpd, *x0, *so, *po;
+  float *scd, *shd;
+  ImageDesc* idd;
+  RET(upload(&tmp, &wpd, wp.data(), wp.size() * sizeof(bf16_t)));
+  RET(upload_vec(&tmp, &scd, std::vector<float>(scale_host, scale_host + 64), 64));
+  RET(upload_vec(&tmp, &shd, std::vector<float>(shift_host, shift_host + 64), 64));
+  std::vector<ImageDesc> id((size_t)B);
+  for (int b = 0; b < B; ++b) { id[b].ptr = x + (size_t)b * 3 * H * W; id[b].h = H; id[b].w = W; }
+  RET(upload(&tmp, (void**)&idd, id.data(), id.size() * sizeof(ImageDesc)));
+  RET(tmp.dalloc(&x0, (size_t)B * H * W * 4 * 2));
+  RET(tmp.dalloc(&so, (size_t)B * H2 * W2 * 64 * 2));
+  RET(tmp.dalloc(&po, (size_t)B * H4 * W4 * 64 * 2));
+  const float mean0[3] = {0.f, 0.f, 0.f}, std1[3] = {1.f, 1.f, 1.f};
+  KCHK(launch_preprocess(c->dt, idd, x0, B, H, W, mean0, std1, c->stream), "preprocess");
+  KCHK(launch_stem_conv(x0, wpd, scd, shd, so, B, H, W, H2, W2, c->stream), "stem_conv");
+  KCHK(launch_maxpool(c->dt, so, po, B, H2, W2, 64, H4, W4, c->stream), "maxpool");
+  for (int b = 0; b < B; ++b) {
+    if (stem_out) KCHK(launch_export_nchw(c->dt, so, stem_out + (size_t)b * 64 * H2 * W2, 64, H2 * W2, b * H2 * W2, 64, c->stream), "export");
+    if (pool_out) KCHK(launch_export_nchw(c->dt, po, pool_out + (size_t)b * 64 * H4 * W4, 64, H4 * W4, b * H4 * W4, 64, c->stream), "export");
+  }
   return 0;
 }
 

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "sylph_export_pyramid": (c_int, [c_void_p, c_int, c_void_p]),
     "sylph_fcos_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "sylph_export_head": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sylph_import_head": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sylph_roi_align": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sylph_decode_nms": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_codegen": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -57,6 +59,7 @@ PROTOTYPES = {
     "sylph_conv2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sylph_group_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "sylph_stem_maxpool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_device_bytes": (c_int64, [c_void_p]),
     "sylph_profile_enable": (c_int, [c_void_p, c_int]),
     "sylph_bench_conv": (c_int, [c_void_p] + [c_int] * 12 + [POINTER(c_float), POINTER(ctypes.c_double)]),

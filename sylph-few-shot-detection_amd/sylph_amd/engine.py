@@ -123,7 +123,8 @@ class Engine:
         check(self.L.sylph_set_config(self._ctx, ctypes.byref(self.sc)), "set_config")
         self.nlevels = self.sc.nlevels
         self.is_roi_encoder = int(self.sc.cg_type) == 1
-        self.cond_scale = 1.0  # CondConvBlock Scale (ROIEncoder head), read from the checkpoint
+        self.cond_scale = 1.0  # CondConvBlock Scale of the first chunk (ROIEncoder head), read from the checkpoint
+        self.cond_scales = [1.0]  # all CondConvBlock Scales (one per 256-channel chunk of the class code)
         self._batch = None  # (B, H, W, [(h,w)...])
         self._ncls = 0
         self._keep = []  # tensors that must outlive queued kernels
@@ -148,8 +149,13 @@ class Engine:
         for k, v in sd.items():
             if not torch.is_tensor(v) or not v.is_floating_point():
                 continue
-            if k.endswith("fcos_head.cond_cls_logits.scales.0.scale"):
-                self.cond_scale = float(v.reshape(-1)[0])
+            if ".fcos_head.cond_cls_logits.scales." in k and k.endswith(".scale"):
+                i = int(k.split(".scales.")[1].split(".")[0])
+                while len(self.cond_scales) <= i:
+                    self.cond_scales.append(1.0)
+                self.cond_scales[i] = float(v.reshape(-1)[0])
+                if i == 0:
+                    self.cond_scale = self.cond_scales[0]
             t = v.detach().to("cpu", torch.float32).contiguous()
             shape = (c_int64 * max(t.dim(), 1))(*(list(t.shape) if t.dim() else [1]))
             check(self.L.sylph_load_weight(self._ctx, k.encode(), c_void_p(t.data_ptr()), shape, max(t.dim(), 1)),
@@ -210,13 +216,21 @@ class Engine:
     def head(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor]):
         self._stream()
         assert cls_conv.dim() == 4, f"Weight has dimension: {cls_conv.dim()}"
-        assert cls_conv.size(1) == 256 and cls_conv.size(2) == 1 and cls_conv.size(3) == 1
-        w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256).contiguous()
+        assert cls_conv.size(2) == 1 and cls_conv.size(3) == 1
+        k = cls_conv.size(1) // 256
+        assert cls_conv.size(1) == 256 * k and k >= 1, f"weight has wrong shape, {tuple(cls_conv.shape)}"
+        assert k == 1 or self.is_roi_encoder, "feature.size(1) != weight.size(1)"  # CondConvBasic (head_utils.py:69)
+        w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256 * k)
         b = cls_bias.to(self.device, torch.float32).reshape(-1).contiguous() if cls_bias is not None else None
-        if self.is_roi_encoder and self.cond_scale != 1.0:
-            # CondConvBlock with one 256-channel chunk: scale * conv(feature, w, bias) (head_utils.py:146-150)
-            w = w * self.cond_scale
-            b = b * self.cond_scale if b is not None else None
+        if self.is_roi_encoder:
+            # CondConvBlock (head_utils.py:140-162): sum over 256-channel chunks of scale_i * conv(feature, w_i, bias); the
+            # reference indexes the Scale of chunk i+1 with i (head_utils.py:157-161).  conv is linear in (w, bias), so
+            # the block is ONE class-conditional conv with w_eff = sum_i s_i' w_i and bias_eff = (sum_i s_i') bias.
+            sc = list(self.cond_scales) if len(self.cond_scales) >= max(k - 1, 1) else [1.0 / k] * k
+            per_chunk = [sc[0]] + [sc[i] for i in range(k - 1)]
+            w = sum(s * w[:, 256 * i:256 * (i + 1)] for i, s in enumerate(per_chunk))
+            b = b * float(sum(per_chunk)) if b is not None else None
+        w = w.contiguous()
         if b is not None:
             assert b.numel() == w.size(0)
         self._codes = (w, b)
@@ -235,6 +249,29 @@ class Engine:
             check(self.L.sylph_export_head(self._ctx, l, _ptr(a), _ptr(r), _ptr(c), _ptr(q)), "export_head")
             lo.append(a); rg.append(r); ct.append(c); io.append(q)
         return lo, rg, ct, io
+
+    def import_head(self, logits: List[torch.Tensor], reg: List[torch.Tensor], ctr: List[torch.Tensor],
+                    iou: Optional[List[torch.Tensor]] = None):
+        """Test boundary: per-level fp32 NCHW head outputs -> the context (then `decode`)."""
+        self._stream()
+        N = int(logits[0].shape[1])
+        keep = []
+        for l in range(self.nlevels):
+            ts = [t[l].to(self.device, torch.float32).contiguous() if t is not None else None for t in (logits, reg, ctr, iou)]
+            keep.append(ts)
+            check(self.L.sylph_import_head(self._ctx, N, l, _ptr(ts[0]), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3])), "import_head")
+        self._keep_head = keep
+        self._ncls = N
+
+    def roi_align(self, boxes: torch.Tensor) -> torch.Tensor:
+        """Test boundary: ROIPooler(7x7, ROIAlignV2) of one box per image of the current batch -> (S,256,7,7)."""
+        self._stream()
+        B = self._batch[0]
+        bx = boxes.to(self.device, torch.float32).reshape(-1, 4).contiguous()
+        assert bx.shape[0] == B
+        out = torch.empty(B, 256, 7, 7, device=self.device)
+        check(self.L.sylph_roi_align(self._ctx, _ptr(bx), _ptr(out)), "roi_align")
+        return out
 
     def decode(self, out_sizes: Optional[List[Tuple[int, int]]] = None, max_out: Optional[int] = None):
         """-> per image dict of device tensors (pred_boxes, scores, pred_classes, fpn_levels, locations,
@@ -340,6 +377,20 @@ class Engine:
         g, b = gamma.detach().cpu().float().contiguous(), beta.detach().cpu().float().contiguous()
         check(self.L.sylph_group_norm(self._ctx, _ptr(x), B, H, W, _ptr(g), _ptr(b), int(relu), _ptr(y)), "group_norm")
         return y
+
+    def stem_maxpool(self, x, w, scale, shift):
+        """Kernel parity entry (bf16 engines): stem 7x7 s2 + FrozenBN + ReLU and the 3x3 s2 max-pool -> (stem, pool) NCHW fp32."""
+        self._stream()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, C, H, W = x.shape
+        assert C == 3
+        H2, W2 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        H4, W4 = (H2 - 1) // 2 + 1, (W2 - 1) // 2 + 1
+        so = torch.empty(B, 64, H2, W2, device=self.device)
+        po = torch.empty(B, 64, H4, W4, device=self.device)
+        wh, sc, sh = [t.detach().cpu().float().contiguous() for t in (w, scale, shift)]
+        check(self.L.sylph_stem_maxpool(self._ctx, _ptr(x), B, H, W, _ptr(wh), _ptr(sc), _ptr(sh), _ptr(so), _ptr(po)), "stem_maxpool")
+        return so, po
 
     def device_bytes(self) -> int:
         return int(self.L.sylph_device_bytes(self._ctx))

@@ -8,6 +8,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+STRIDES = np.array([8, 16, 32, 64, 128])
+
+
+def _assert_boxes(got, want, levels):
+    """|dbox| <= 2.5e-4 * stride + 1e-3 px: a box is location -+ reg * stride, see tests/test_hip_parity.py::_assert_boxes."""
+    got, want, levels = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(levels)
+    err = np.abs(got - want)
+    assert (err <= 2.5e-4 * STRIDES[levels][:, None] + 1e-3).all(), f"max box error {err.max():.4g} px"
+
 
 def _cfg():
     from sylph_amd.runner import MetaFCOSRunner, create_cfg
@@ -74,7 +83,7 @@ def test_runner_episode_matches_oracle(model, sd):
             np.testing.assert_array_equal(inst.fpn_levels.cpu().numpy(), w["fpn_levels"].numpy())
             np.testing.assert_array_equal(inst.locations.cpu().numpy(), w["locations"].numpy())
             np.testing.assert_allclose(inst.scores.cpu().numpy(), w["scores"].numpy(), atol=1e-3)
-            np.testing.assert_allclose(inst.pred_boxes.tensor.cpu().numpy(), w["pred_boxes"].numpy(), atol=2e-2, rtol=1e-3)
+            _assert_boxes(inst.pred_boxes.tensor.cpu().numpy(), w["pred_boxes"].numpy(), w["fpn_levels"].numpy())
 
 
 def test_model_contract_errors(model):
@@ -132,4 +141,5 @@ def test_predictor_roundtrip(sd, tmp_path, model):
     want = E.forward_instances([x], codes, sd, out_sizes=[(90, 130)])[0]
     assert out.image_size == (90, 130) and len(out) == want["scores"].numel() and len(out) > 0
     np.testing.assert_allclose(out.scores.cpu().numpy(), want["scores"].numpy(), atol=1e-3)
-    np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), want["pred_boxes"].numpy(), atol=2e-2, rtol=1e-3)
+    # boxes are rescaled to the 90 x 130 original by detector_postprocess (factor <= 1 here): same bound
+    _assert_boxes(out.pred_boxes.tensor.cpu().numpy(), want["pred_boxes"].numpy(), want["fpn_levels"].numpy())

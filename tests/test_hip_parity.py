@@ -270,7 +270,7 @@ def test_full_episode_matches_oracle_f32(full_sd):
         assert gv["scores"].numel() == wv["scores"].numel()
         np.testing.assert_array_equal(gv["cand_index"].cpu().numpy(), _cand_ordinals(wv, 128, 160, 5))
         np.testing.assert_allclose(gv["scores"].cpu().numpy(), wv["scores"].numpy(), atol=1e-3)
-        np.testing.assert_allclose(gv["pred_boxes"].cpu().numpy(), wv["pred_boxes"].numpy(), atol=2e-2, rtol=1e-3)
+        _assert_boxes(gv["pred_boxes"].cpu().numpy(), wv["pred_boxes"].numpy(), wv["fpn_levels"].numpy())
         np.testing.assert_array_equal(gv["pred_classes"].cpu().numpy(), wv["pred_classes"].numpy())
 
 
@@ -470,3 +470,190 @@ def test_c5_query_shape_runs_bf16():
     pyr = eng.export_pyramid()
     assert [tuple(p.shape[-2:]) for p in pyr] == [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)]
     assert all(bool(torch.isfinite(p.float()).all()) for p in pyr)
+
+
+# --------------------------------------------------------------------------------- round-2 additions
+STRIDES = np.array([8, 16, 32, 64, 128])
+
+
+def _assert_boxes(got, want, levels, what=""):
+    """Boxes are location -+ reg * stride, so an error eps in the regression map is eps * stride pixels.  The north-star
+    bound (1e-3 on the fp32 network outputs, checked directly on the reg maps by the head golden test) therefore
+    reads |dbox| <= 1e-3 * stride; measured on MI355X: <= 2e-4 * stride (fp32 summation order of the 2304-term
+    tower dot products, 4 layers deep).  We assert the measured bound with a small floor for the postprocess rescale."""
+    got, want, levels = np.asarray(got, np.float64), np.asarray(want, np.float64), np.asarray(levels)
+    tol = 2.5e-4 * STRIDES[levels][:, None] + 1e-3
+    err = np.abs(got - want)
+    assert (err <= tol).all(), f"{what} max box error {err.max():.4g} px; worst err/stride {(err / STRIDES[levels][:, None]).max():.3g}"
+
+
+def test_stem_and_maxpool_kernels_bf16_vs_torch():
+    """stem_conv_kernel (7x7 s2 p3, Cin 3, bf16) and maxpool_kernel directly, on sizes with ragged 8 x 16 tiles."""
+    g = torch.Generator().manual_seed(11)
+    for B, H, W in ((2, 64, 96), (1, 75, 118), (3, 33, 47)):
+        x = _bf16_round(torch.randn(B, 3, H, W, generator=g) * 60.0)
+        w = _bf16_round(torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5 / 60.0)
+        scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+        eng = _engine("bf16")
+        so, po = eng.stem_maxpool(x, w, scale, shift)
+        ref = F.relu(F.conv2d(x, w, None, 2, 3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        assert so.shape == ref.shape
+        err = (so.cpu() - ref).abs().max().item()
+        assert err <= 1e-2 * max(1.0, ref.abs().max().item()), f"stem {B}x{H}x{W}: max err {err}"
+        # the max of bf16 values is exact: the pool must equal torch's pool of the kernel's own stem output bit for bit
+        assert torch.equal(po.cpu(), F.max_pool2d(so.cpu(), 3, 2, 1)), f"maxpool {B}x{H}x{W}"
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_cond_conv_block_matches_reference_golden(golden_dir, k):
+    """CondConvBlock (ROIEncoder head, head_utils.py:121-162) with one and two 256-channel chunks vs the reference's
+    own output (g5 ccb1 / ccb2).  NUM_CLS_CONVS = 0 makes the class-conditional conv read the imported features."""
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g5_reduce_condblock.npz"))
+    cfg = _roienc_cfg()
+    cfg.MODEL.FCOS.NUM_CLS_CONVS = 0
+    cfg.MODEL.FCOS.NUM_BOX_CONVS = 0
+    eng = _engine("f32", cfg)
+    sd = W.head_state_dict(seed=1, num_classes=60)
+    for i in range(k):
+        sd[f"proposal_generator.fcos_head.cond_cls_logits.scales.{i}.scale"] = torch.tensor([1.0 / k])  # Scale init (head_utils.py:131-136)
+    eng.load_state_dict(sd)
+    feat = torch.from_numpy(g["ccb_feat"])
+    eng.import_pyramid([feat] + [torch.zeros(2, 256, h, w) for h, w in ((3, 3), (2, 2), (1, 1), (1, 1))], (40, 48))
+    eng.head(torch.from_numpy(g[f"ccb{k}_w"]), torch.from_numpy(g[f"ccb{k}_b"]))
+    lo, _, _, _ = eng.export_head()
+    np.testing.assert_allclose(lo[0].cpu().numpy(), g[f"ccb{k}_y"], atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("lvis", [False, True])
+def test_codegen_10_shot_matches_reference_golden(golden_dir, lvis):
+    """BASELINE config C3 support path: 10 shots of one class (mean over shots) + normalisation vs the reference."""
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g3b_codegen_s10.npz"))
+    eng = _engine("f32", _cfg(lvis))
+    eng.load_state_dict(W.codegen_state_dict(seed=2))
+    eng.import_pyramid(_feats(g, "s10_feat"), (128, 160))
+    code = eng.codegen(torch.from_numpy(g["s10_boxes"]))
+    tag = f"{'lvis' if lvis else 'coco'}_s10"
+    np.testing.assert_allclose(code[:256].cpu().numpy(), g[f"{tag}_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(code[256].item(), g[f"{tag}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
+    out = eng.normalize_codes(code.reshape(1, 257).clone().contiguous()).cpu().numpy()
+    np.testing.assert_allclose(out[0, :256], g[f"{tag}_norm_cls_conv"].reshape(-1), atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(out[0, 256], g[f"{tag}_norm_cls_bias"].reshape(-1)[0], atol=1e-4, rtol=1e-3)
+
+
+def test_full_size_f32_matches_oracle(full_sd):
+    """Two 800x1333 queries (ragged batch), 5-way, fp32 mode, DEFAULT kernel selection (no SYLPH_* knob): the production
+    tile shapes, the XCD map with many M tiles per XCD, the fused top-down / shortcut paths -- against the CPU oracle.
+    Three statements, each as strict as it can meaningfully be:
+      (1) network outputs: logits / reg / ctrness / iou of all 22 400 locations within 1e-3 (the north-star bound);
+      (2) decode + NMS + top-k + postprocess: the oracle decoder run on the HIP head outputs yields IDENTICAL candidates
+          (exact index equality; scores 1e-5, boxes 1e-3 px);
+      (3) end to end (two fp32 conv stacks with different summation orders feeding threshold / IoU > 0.6 / top-100
+          decisions): >= 95 % of the oracle's detections are reproduced with the same (level, location, class), their
+          scores within 1e-3 and boxes within the stride-relative bound."""
+    from oracle import backbone as OB, decode as OD, head as OH
+    from sylph_amd import synthetic as W
+    assert not any(k.startswith("SYLPH_CONV") for k in os.environ), "this test must run with the default kernel selection"
+    eng = _engine("f32", _cfg())
+    eng.load_state_dict(full_sd)
+    q = W.synthetic_images(2, 800, 1333, seed=3)
+    q[1] = q[1][:, :750, :1200].contiguous()  # ragged batch: second image padded on both axes
+    codes = W.synthetic_codes(5, seed=4, scale=3.0)
+    x, sizes = OB.preprocess(q)
+    ref_head = OH.fcos_head(OB.backbone_fpn(x, full_sd, 50), full_sd, codes)
+    assert eng.preprocess(q) == (800, 1344)
+    eng.backbone()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    hip_head = [[t.cpu() for t in ts] for ts in eng.export_head()]
+    got = eng.decode()
+    for name, hs, rs in zip(("logits", "reg", "ctrness", "iou"), hip_head, ref_head):  # (1)
+        for l in range(5):
+            err = (hs[l] - rs[l]).abs().max().item()
+            assert err <= 1e-3, f"{name} level {l}: max err {err}"
+    want_on_hip = OD.predict_proposals(*hip_head)  # (2)
+    want = OD.predict_proposals(*ref_head)
+    for i in range(2):
+        wh = OD.detector_postprocess(want_on_hip[i], sizes[i], sizes[i][0], sizes[i][1])
+        gv = got[i]
+        assert gv["scores"].numel() == wh["scores"].numel() >= 50
+        np.testing.assert_array_equal(gv["cand_index"].cpu().numpy(), _cand_ordinals(wh, 800, 1344, 5))
+        np.testing.assert_allclose(gv["scores"].cpu().numpy(), wh["scores"].numpy(), atol=1e-5)
+        np.testing.assert_allclose(gv["pred_boxes"].cpu().numpy(), wh["pred_boxes"].numpy(), atol=1e-3)
+        wv = OD.detector_postprocess(want[i], sizes[i], sizes[i][0], sizes[i][1])  # (3)
+        ref_ord, hip_ord = _cand_ordinals(wv, 800, 1344, 5), gv["cand_index"].cpu().numpy()
+        pos = {int(o): k for k, o in enumerate(hip_ord)}
+        hit = np.array([o in pos for o in ref_ord.tolist()])
+        print(f"full-size fp32 image {i}: {hit.sum()} of {hit.size} oracle detections reproduced exactly")
+        assert hit.mean() >= 0.95, hit.mean()
+        sel = np.array([pos[int(o)] for o in ref_ord[hit].tolist()])
+        np.testing.assert_allclose(gv["scores"].cpu().numpy()[sel], wv["scores"].numpy()[hit], atol=1e-3)
+        _assert_boxes(gv["pred_boxes"].cpu().numpy()[sel], wv["pred_boxes"].numpy()[hit], wv["fpn_levels"].numpy()[hit], f"image {i}")
+
+
+def _match_stats(got, want):
+    """Fraction of oracle detections that have a HIP detection of the same class with IoU >= 0.9, and the largest score
+    difference over those matches."""
+    gb, gc, gs = got["pred_boxes"].float().cpu(), got["pred_classes"].cpu(), got["scores"].float().cpu()
+    wb, wc, ws = want["pred_boxes"], want["pred_classes"], want["scores"]
+    if wb.numel() == 0 or gb.numel() == 0:
+        return 0.0, 0.0
+    lt = torch.max(wb[:, None, :2], gb[None, :, :2])
+    rb = torch.min(wb[:, None, 2:], gb[None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(-1)
+    aw = (wb[:, 2] - wb[:, 0]) * (wb[:, 3] - wb[:, 1])
+    ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+    iou = inter / (aw[:, None] + ag[None, :] - inter)
+    iou = torch.where(wc[:, None] == gc[None, :], iou, torch.zeros_like(iou))
+    best, idx = iou.max(dim=1)
+    ok = best >= 0.9
+    ds = (gs[idx] - ws).abs()[ok]
+    return float(ok.float().mean()), float(ds.max()) if ds.numel() else 0.0
+
+
+def test_c3_full_size_batch16_20way_bf16(full_sd):
+    """BASELINE config C3 query path at full size: 20-way, batch 16 of 800x1333, bf16 (the production mode: halo / hpipe
+    kernels, stem kernel).  Size-independent properties on all 16 images, and detection-level agreement with the fp32
+    CPU oracle on one of them (same class + IoU >= 0.9 for >= 90 % of the oracle's detections; bf16 storage moves a few
+    scores across the NMS / top-100 boundary)."""
+    from oracle import episode as E
+    from sylph_amd import synthetic as W
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(full_sd)
+    q = W.synthetic_images(16, 800, 1333, seed=41)
+    codes = W.synthetic_codes(20, seed=42, scale=3.0)
+    assert eng.preprocess(q) == (800, 1344)
+    eng.backbone()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    dets = eng.decode()
+    assert len(dets) == 16
+    for d in dets:
+        s, bx = d["scores"].float().cpu(), d["pred_boxes"].float().cpu()
+        assert s.numel() > 0 and torch.isfinite(s).all() and (s[:-1] >= s[1:]).all()
+        assert int(d["pred_classes"].max()) < 20
+        assert (bx[:, 0] >= 0).all() and (bx[:, 2] <= 1333).all() and (bx[:, 1] >= 0).all() and (bx[:, 3] <= 800).all()
+    want = E.forward_instances(q[5:6], codes, full_sd)[0]
+    frac, dscore = _match_stats(dets[5], want)
+    print(f"C3 bf16 vs fp32 oracle: matched {frac:.3f} of {want['scores'].numel()} detections, max |dscore| {dscore:.4f}")
+    assert frac >= 0.9 and dscore <= 0.05, (frac, dscore)
+
+
+def test_c3_support_path_10_shot_full_size_bf16(full_sd):
+    """BASELINE config C3 support path at full size: one class, 10 support images of 800x1333, bf16, vs the fp32 CPU
+    oracle (cosine of the un-normalised 256-d code and of the normalised one)."""
+    from oracle import codegen as CG, episode as E
+    from sylph_amd import synthetic as W
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(full_sd)
+    sup = W.synthetic_images(10, 800, 1333, seed=61)
+    boxes = W.synthetic_boxes(10, 800, 1333, seed=62)
+    eng.preprocess(sup)
+    eng.backbone()
+    code = eng.codegen(boxes)
+    ref = E.forward_class_code(sup, boxes, full_sd)
+    cos = F.cosine_similarity(code[:256].float().cpu(), ref["cls_conv"].reshape(-1), dim=0).item()
+    assert cos > 0.99, cos
+    normed = eng.normalize_codes(code.reshape(1, 257).clone().contiguous()).cpu()
+    rc, rb = CG.normalize_code(ref["cls_conv"], ref["cls_bias"], full_sd)
+    assert F.cosine_similarity(normed[0, :256], rc.reshape(-1), dim=0).item() > 0.99
+    assert abs(normed[0, 256].item() - rb.item()) < 5e-2
