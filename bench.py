@@ -58,7 +58,7 @@ def dev_images(n, h, w, seed, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="query images per GPU per step")
     ap.add_argument("--ways", type=int, default=5)
@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket conv launches with HIP events (roofline fields become 0)")
     ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--no-sweep", action="store_true", help="skip the untimed batch-size sweep / fp32 legs")
+    ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-oracle agreement leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,7 +124,8 @@ def main():
     cls_conv = (codes[:, :256] * args.code_scale).reshape(N, 256, 1, 1).contiguous()
     cls_bias = codes[:, 256].contiguous()
     torch.cuda.synchronize()
-    setup = {"codegen_s": t1 - t0, "allgather_s": t2 - t1, "support_images": (c1 - c0) * S}
+    setup = {"codegen_s": t1 - t0, "code_gather_and_order_s": t2 - t1, "code_gather_is_collective": world > 1,
+             "support_images": (c1 - c0) * S}
 
     # ---- query steps -----------------------------------------------------------------------------
     queries = dev_images(B, H, Wd, 7 + rank, device)
@@ -174,6 +177,42 @@ def main():
             split["backbone_ms"] += p1["conv_ms"]; split["backbone_flops"] += p1["conv_flops"]
             split["head_ms"] += p2["conv_ms"]; split["head_flops"] += p2["conv_flops"]
     eng.profile_enable(False)
+    # ---- untimed extra legs (rank 0, one GPU): batch-size sweep in the reference protocol, fp32 mode, bf16 agreement ----
+    sweep, fp32_img_s, parity = None, None, None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        sweep = {}
+        for b in (1, 8, 16, 64):
+            if b == B:
+                continue
+            qs = queries[:b] if b <= B else dev_images(b, H, Wd, 7, device)
+
+            def step_b():
+                eng.preprocess(qs); eng.backbone(); eng.head(cls_conv, cls_bias)
+                return eng.decode()
+            for _ in range(5):  # the reference excludes 5 warm-up iterations (meta_learn_evaluation.py:392-417)
+                step_b()
+            torch.cuda.synchronize()
+            n = 20 if b == 1 else 6
+            ts = time.perf_counter()
+            for _ in range(n):
+                step_b()  # synchronous: decode() ends on the count read-back, as the reference loop ends on cuda.synchronize
+            torch.cuda.synchronize()
+            sweep[f"B{b}"] = round(b * n / (time.perf_counter() - ts), 1)
+        # fp32 mode (the mode with <= 1e-3 parity against the oracle): exact-fp32 MFMA, same kernels
+        e32 = Engine(cfg, dtype="f32", device=local_rank)
+        e32.load_state_dict(sd)
+        q8 = queries[:8]
+        for _ in range(2):
+            e32.preprocess(q8); e32.backbone(); e32.head(cls_conv, cls_bias); e32.decode()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(3):
+            e32.preprocess(q8); e32.backbone(); e32.head(cls_conv, cls_bias); e32.decode()
+        torch.cuda.synchronize()
+        fp32_img_s = round(8 * 3 / (time.perf_counter() - ts), 1)
+        e32.close()
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity = parity_bf16(sd, queries[:2], cls_conv, cls_bias, dets[:2])
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,11 +227,12 @@ def main():
         images_timed = B * args.steps
         alg_flops = GFLOP_PER_IMAGE_MFMA_CONV * 1e9 * images_timed  # all conv launches of the region, this rank
         achieved = alg_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_per_launch(B, launches // max(args.steps, 1))
         roofline = {
-            "kernel": "conv_igemm_kernel (+ stem_conv_kernel): implicit-GEMM MFMA convs, every conv launch of the timed region",
+            "kernel": "conv_igemm_kernel + conv_hpipe_kernel (+ stem_conv_kernel): implicit-GEMM MFMA convs, every conv launch of the timed region",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-            "traffic": pmc_traffic_per_launch(B, launches // max(args.steps, 1)),
+            "traffic": traffic, "traffic_source": traffic_src,
             "launches": launches, "avg_launch_us": round(conv_s / launches * 1e6, 2),
             "algorithmic_gflop_per_launch": round(alg_flops / launches / 1e9, 3),
             "gflop_counted_by_library_per_image": round(prof["conv_flops"] / images_timed / 1e9, 2),
@@ -218,6 +258,13 @@ def main():
             "episode_setup": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in setup.items()},
             "roofline": roofline,
         }
+        if sweep is not None:
+            sweep[f"B{B}"] = round(value, 1)
+            out["sweep"] = {"unit": "images/s", "protocol": "synchronous steps (decode read-back per step), 5 warm-up steps; the headline value "
+                            f"keeps {args.inflight} steps in flight", **sweep}
+            out["fp32_img_s"] = fp32_img_s
+        if parity is not None:
+            out["parity_bf16"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, queries, cls_conv, cls_bias, args.cpu_images)
         print(json.dumps(out), flush=True)
@@ -226,15 +273,49 @@ def main():
 
 
 def pmc_traffic_per_launch(batch, launches_per_step):
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (separate runs of this same
-    command: FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as is; tools/rocpd_pmc.py).
-    Scaled from the profiled batch to this run's batch (traffic is per image); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r1_f_pmc_hbm_traffic.json")
-    if not os.path.exists(path) or launches_per_step <= 0:
-        return None
-    with open(path) as f:
-        d = json.load(f)
-    return round(d["hbm_bytes_per_image"] * batch / launches_per_step)
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (separate runs of this same command, as the
+    guide prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE calibrated on preprocess_kernel; tools/rocpd_pmc.py).
+    Scaled from the profiled batch to this run's batch (traffic is per image).  Returns (bytes or None, source label)."""
+    for name in ("r2_pmc_hbm_traffic.json", "r1_f_pmc_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path) and launches_per_step > 0:
+            with open(path) as f:
+                d = json.load(f)
+            return round(d["hbm_bytes_per_image"] * batch / launches_per_step), {
+                "file": "profiles/" + name, "profiled_batch": d.get("batch"), "hbm_bytes_per_image": round(d["hbm_bytes_per_image"]),
+                "note": "separate rocprofv3 --pmc passes of this command (not collected in this run)"}
+    return None, None
+
+
+def parity_bf16(sd, queries, cls_conv, cls_bias, dets):
+    """Agreement of the timed (bf16) configuration with the fp32 CPU oracle on the first query images: fraction of the
+    oracle's detections that the HIP path reproduces (same class, IoU >= 0.9) and the largest score difference over
+    those.  The oracle is the checker here, never the thing measured."""
+    from oracle import episode as E
+    codes = {"cls_conv": cls_conv.cpu(), "cls_bias": cls_bias.cpu()}
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    matched, total, dmax = 0, 0, 0.0
+    with torch.no_grad():
+        for q, d in zip(queries, dets):
+            w = E.forward_instances([q.cpu()], codes, sd)[0]
+            gb, gc, gs = d["pred_boxes"].float().cpu(), d["pred_classes"].cpu(), d["scores"].float().cpu()
+            wb, wc, ws = w["pred_boxes"], w["pred_classes"], w["scores"]
+            total += int(ws.numel())
+            if wb.numel() == 0 or gb.numel() == 0:
+                continue
+            lt = torch.max(wb[:, None, :2], gb[None, :, :2])
+            rb = torch.min(wb[:, None, 2:], gb[None, :, 2:])
+            inter = (rb - lt).clamp(min=0).prod(-1)
+            aw, ag = (wb[:, 2] - wb[:, 0]) * (wb[:, 3] - wb[:, 1]), (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+            iou = inter / (aw[:, None] + ag[None, :] - inter)
+            iou = torch.where(wc[:, None] == gc[None, :], iou, torch.zeros_like(iou))
+            best, idx = iou.max(dim=1)
+            ok = best >= 0.9
+            matched += int(ok.sum())
+            if ok.any():
+                dmax = max(dmax, float((gs[idx] - ws).abs()[ok].max()))
+    return {"matched_frac": round(matched / max(total, 1), 4), "max_abs_dscore": round(dmax, 5), "n_ref": total,
+            "images": len(queries), "criterion": "same class and IoU >= 0.9 against the fp32 CPU oracle's detections"}
 
 
 def cpu_baseline(sd, queries, cls_conv, cls_bias, n_images):
