@@ -117,7 +117,7 @@ def main():
         packed = torch.zeros(0, D.ROW, device=device)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    rows = D.order_by_class_id(D.gather_packed_codes(packed), N)
+    rows = D.scatter_by_class_id(D.gather_packed_codes(packed, D.shard_capacity(N, world)), N)  # ONE collective, no host sync
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     codes = eng.normalize_codes(rows[:, :257].contiguous())

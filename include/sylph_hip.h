@@ -135,8 +135,19 @@ int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
  * one XYXY box per image; out_nchw_dev (S,256,7,7) fp32. */
 int sylph_roi_align(sylph_ctx* ctx, const float* boxes_dev, float* out_nchw_dev);
 
-/* CodeGeneratorHead.forward_normalize_code (code_generator.py:832-897): codes_dev (n,257) in place. */
-int sylph_normalize_codes(sylph_ctx* ctx, float* codes_dev, int n);
+/* CodeGeneratorHead.forward_normalize_code (code_generator.py:832-897): codes_dev (n,257) in place.
+ * weight_norm_dev: (n) cls_weight_norm factors applied after the L2 normalisation (code_generator.py:838-840), or NULL. */
+int sylph_normalize_codes(sylph_ctx* ctx, float* codes_dev, int n, const float* weight_norm_dev);
+
+/* reduce_class_code + replace ordering (sylph/modeling/code_generator/utils.py:376-427; the cross-rank step of the
+ * base-class "use all ground truths" path, sylph/evaluation/meta_learn_evaluation.py:118-254): rows_dev (n, row_ld) packed
+ * chunk codes = cls_conv[256] | cls_bias | acc_weight | class id | valid | cls_weight_norm | has_weight_norm | payload;
+ * the rows of a class are summed in row order (acc_weight in double).  divide_by_acc != 0: the cross-rank reduce (sums
+ * divided by the accumulated weight when |1 - acc| > 1e-6, acc_weight := 1); == 0: the per-rank accumulation of
+ * len/total_len-weighted chunk codes (meta_learn_evaluation.py:176-188; acc_weight := accumulated weight).
+ * out_dev (num_classes, row_ld): row c = class id c (valid = 0 when no chunk of that class exists). */
+int sylph_reduce_codes(sylph_ctx* ctx, const float* rows_dev, int n, int row_ld, float* out_dev, int num_classes,
+                       int divide_by_acc);
 
 /* Primitive entries used by the kernel parity tests (F.conv2d / F.group_norm equivalents).
  * x: (B,C,H,W) fp32 NCHW device; w_host: (Cout,Cin,KH,KW) fp32 host; scale/shift host (Cout) or NULL;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void normalize_codes_kernel(float* __restrict_
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int post_norm,
                                                               int l2_norm, float conv_scale, float bias_scale,
-                                                              float bias_prior) {
+                                                              float bias_prior, const float* __restrict__ weight_norm) {
   float* code = codes + (size_t)blockIdx.x * (C + 1);
   const int c = threadIdx.x;
   float v = c < C ? code[c] : 0.f;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void normalize_codes_kernel(float* __restrict_
     const float nrm = fmaxf(sqrtf(part[0] + part[1] + part[2] + part[3]), 1e-12f);
     v = v / nrm;
   }
+  if (weight_norm) v = v * weight_norm[blockIdx.x];  // x cls_weight_norm (code_generator.py:838-840)
   v = v * conv_scale;
   if (c < C) code[c] = v;
   if (c == 0) code[C] = code[C] * bias_scale + bias_prior;
@@ -163,10 +164,63 @@ __global__ __launch_bounds__(256) void normalize_codes_kernel(float* __restrict_
 
 int launch_normalize_codes(float* codes, int ncodes, int C, const float* gn_gamma, const float* gn_beta,
                            int post_norm, int l2_norm, float conv_scale, float bias_scale, float bias_prior,
-                           hipStream_t s) {
+                           const float* weight_norm, hipStream_t s) {
   if (C != 256) return -1;
   hipLaunchKernelGGL(normalize_codes_kernel, dim3(ncodes), dim3(256), 0, s, codes, C, gn_gamma, gn_beta, post_norm,
-                     l2_norm, conv_scale, bias_scale, bias_prior);
+                     l2_norm, conv_scale, bias_scale, bias_prior, weight_norm);
+  return (int)hipGetLastError();
+}
+
+// reduce_class_code (sylph/modeling/code_generator/utils.py:397-427) on packed rows, one block per class id.
+// Row layout (fp32, ld >= 262): [0,256) cls_conv | 256 cls_bias | 257 acc_weight | 258 class id | 259 valid |
+// 260 cls_weight_norm | 261 has_weight_norm | [262, ld) opaque payload (copied from the class's first row).
+// The chunk codes of a class (already weighted by len / total_len, meta_learn_evaluation.py:176-188) are summed in ROW
+// ORDER (= rank order, then arrival order: the reference's list order), acc_weight in double like the reference's Python
+// floats; with divide_by_acc the sums are divided by acc_weight when |1 - acc| > 1e-6 (the cross-rank reduce), without it
+// the row keeps the accumulated weight (the per-rank accumulation).  Output row c = class id c (valid 0 if absent).
+__global__ __launch_bounds__(256) void reduce_codes_kernel(const float* __restrict__ rows, int n, int ld,
+                                                           float* __restrict__ out, int num_classes, int divide_by_acc) {
+  const int cid = blockIdx.x, t = threadIdx.x;
+  __shared__ double s_acc;
+  __shared__ int s_first, s_cnt;
+  float sum = 0.f, sum_bias = 0.f, sum_wn = 0.f, has_wn = 0.f;
+  double acc = 0.0;
+  int first = -1, cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* r = rows + (size_t)i * ld;
+    if (r[259] == 0.f || (int)r[258] != cid) continue;
+    if (first < 0) first = i;
+    ++cnt;
+    sum += r[t];
+    if (t == 0) { sum_bias += r[256]; acc += (double)r[257]; sum_wn += r[260]; has_wn = fmaxf(has_wn, r[261]); }
+  }
+  if (t == 0) { s_acc = acc; s_first = first; s_cnt = cnt; }
+  __syncthreads();
+  float* o = out + (size_t)cid * ld;
+  if (s_cnt == 0) {
+    for (int k = t; k < ld; k += 256) o[k] = 0.f;
+    if (t == 0) o[258] = (float)cid;
+    return;
+  }
+  const double a = s_acc;
+  const bool div = divide_by_acc && fabs(1.0 - a) > 1e-6;
+  const float af = (float)a;
+  o[t] = div ? sum / af : sum;
+  if (t == 0) {
+    o[256] = div ? sum_bias / af : sum_bias;
+    o[257] = divide_by_acc ? 1.f : af;  // plain accumulation keeps the accumulated weight for the next (cross-rank) reduce
+    o[258] = (float)cid;
+    o[259] = 1.f;
+    o[260] = div ? sum_wn / af : sum_wn;
+    o[261] = has_wn;
+  }
+  const float* r0 = rows + (size_t)s_first * ld;
+  for (int k = 262 + t; k < ld; k += 256) o[k] = r0[k];
+}
+
+int launch_reduce_codes(const float* rows, int n, int ld, float* out, int num_classes, int divide_by_acc, hipStream_t s) {
+  if (ld < 262 || num_classes <= 0) return -1;
+  hipLaunchKernelGGL(reduce_codes_kernel, dim3(num_classes), dim3(256), 0, s, rows, n, ld, out, num_classes, divide_by_acc);
   return (int)hipGetLastError();
 }
 

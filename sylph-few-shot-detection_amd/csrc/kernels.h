@@ -93,7 +93,9 @@ int launch_roi_align(DType dt, const void* feats, int ld, const LevelDesc* lv_de
 int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int S, int npos, int C,
                         int bias_l2_norm, int has_bias, float* code_out, hipStream_t s);
 int launch_normalize_codes(float* codes, int ncodes, int C, const float* gn_gamma, const float* gn_beta, int post_norm,
-                           int l2_norm, float conv_scale, float bias_scale, float bias_prior, hipStream_t s);
+                           int l2_norm, float conv_scale, float bias_scale, float bias_prior, const float* weight_norm,
+                           hipStream_t s);
+int launch_reduce_codes(const float* rows, int n, int ld, float* out, int num_classes, int divide_by_acc, hipStream_t s);
 
 // roi_encoder.hip
 struct MsCamWeights {  // fp32 device pointers: conv1x1 256->64, GN(32,64), conv1x1 64->256, GN(32,256); local / global

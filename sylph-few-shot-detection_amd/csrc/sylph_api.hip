@@ -1628,13 +1628,22 @@ int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
   return run_ops(c, P->support_ops, "codegen");
 }
 
-int sylph_normalize_codes(sylph_ctx* c, float* codes, int n) {
+int sylph_normalize_codes(sylph_ctx* c, float* codes, int n, const float* weight_norm) {
   if (!c->has_codegen) return fail("code generator weights were not loaded");
   if (n <= 0) return 0;
   const float prior = -logf((1.f - c->cfg.prior_prob) / c->cfg.prior_prob);
   KCHK(launch_normalize_codes(codes, n, 256, c->cg_post.gamma, c->cg_post.beta, c->cfg.cg_post_norm,
-                              c->cfg.cg_conv_l2_norm, c->cg_conv_scale, c->cg_bias_scale, prior, c->stream),
+                              c->cfg.cg_conv_l2_norm, c->cg_conv_scale, c->cg_bias_scale, prior, weight_norm, c->stream),
        "normalize_codes");
+  return 0;
+}
+
+int sylph_reduce_codes(sylph_ctx* c, const float* rows, int n, int row_ld, float* out, int num_classes, int divide_by_acc) {
+  if (!rows || !out) return fail("NULL argument");
+  if (row_ld < 262) return fail("sylph_reduce_codes: rows must be at least 262 floats wide");
+  if (num_classes <= 0 || n < 0) return fail("sylph_reduce_codes: bad sizes");
+  HIPCHK(hipSetDevice(c->device));
+  KCHK(launch_reduce_codes(rows, n, row_ld, out, num_classes, divide_by_acc, c->stream), "reduce_codes");
   return 0;
 }
 

@@ -55,7 +55,8 @@ PROTOTYPES = {
     "sylph_decode_nms": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_codegen": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "sylph_normalize_codes": (c_int, [c_void_p, c_void_p, c_int]),
+    "sylph_normalize_codes": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "sylph_reduce_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int]),
     "sylph_conv2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sylph_group_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -5,18 +5,28 @@ The path shards naturally: support classes and query images are i
 split across ranks in contiguous blocks (the reference uses detectron2 InferenceSampler,
 sylph/data/build.py:578-592,749-763); the ONLY exchange step is the class-code gather
 (MetaFCOSRunner._gather_class_code, sylph/runner/meta_fcos_runner.py:381-439, which pickles
-Python dicts through all_gather_object).  Here the codes travel as one dense fp32 block per rank
-([n, 260]: cls_conv 256 | cls_bias | acc_weight | class id | valid) in a single all_gather; the payload
-is <= 0.9 MB (866 classes), i.e. latency bound, so one collective with padded equal-size blocks is
-the right shape for the point-to-point xGMI fabric (no ring, no bucketing).
-"""
-from typing import List, Tuple
+Python dicts through all_gather_object).  Here everything a class code carries travels in ONE dense
+fp32 block per rank and ONE collective (all_gather_into_tensor): no pickle, no count exchange, no
+host read-back.  Row layout (ROW = 280 floats = 1120 B):
 
+    [0, 256) cls_conv | 256 cls_bias | 257 acc_weight | 258 class id | 259 valid | 260 cls_weight_norm |
+    261 has_weight_norm | 262-263 pad | [264, 280) class name, 64 raw UTF-8 bytes
+
+Every rank contributes a block of the same, statically known capacity (the InferenceSampler shard size
+ceil(n / world), or num_classes rows indexed by class id for the base-class path); unused rows have
+valid = 0.  The payload is <= 1 MB per rank (866 classes), i.e. latency bound: one collective with
+equal-size blocks is the right shape for the point-to-point xGMI fabric (no ring, no bucketing).
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
 CODE_DIM = 256
-F_BIAS, F_ACC, F_CID, F_VALID, ROW = 256, 257, 258, 259, 260
+F_BIAS, F_ACC, F_CID, F_VALID, F_WNORM, F_HAS_WNORM, F_NAME, NAME_FLOATS = 256, 257, 258, 259, 260, 261, 264, 16
+ROW = F_NAME + NAME_FLOATS
+NAME_BYTES = 4 * NAME_FLOATS
 
 
 def get_world_size() -> int:
@@ -36,66 +46,128 @@ def inference_shard(n: int, rank: int = None, world: int = None) -> Tuple[int, i
     return begin, min(begin + shard, n)
 
 
-def pack_codes(cls_conv: torch.Tensor, cls_bias: torch.Tensor, class_ids, acc_weight=None) -> torch.Tensor:
-    """(n,256[,1,1]), (n,), ids -> (n, 260) fp32 rows."""
+def shard_capacity(n: int, world: int = None) -> int:
+    """Rows every rank reserves in the gather block for n sharded items: the shard size ceil(n / world)."""
+    world = get_world_size() if world is None else world
+    return max((n + world - 1) // world, 1)
+
+
+def _name_floats(names: Optional[Sequence[Optional[str]]], n: int) -> torch.Tensor:
+    raw = np.zeros((n, NAME_BYTES), dtype=np.uint8)
+    if names is not None:
+        for i, s in enumerate(names):
+            if s:
+                b = str(s).encode("utf-8")[:NAME_BYTES]
+                raw[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return torch.from_numpy(raw.view(np.float32).reshape(n, NAME_FLOATS))
+
+
+def pack_codes(cls_conv: torch.Tensor, cls_bias: torch.Tensor, class_ids, acc_weight=None, weight_norm=None,
+               names: Optional[Sequence[Optional[str]]] = None) -> torch.Tensor:
+    """(n,256[,1,1]), (n,), ids -> (n, ROW) fp32 rows (layout above) on the device of cls_conv."""
     n = cls_conv.shape[0]
-    out = torch.zeros(n, ROW, dtype=torch.float32, device=cls_conv.device)
+    dev = cls_conv.device
+    out = torch.zeros(n, ROW, dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
     out[:, :CODE_DIM] = cls_conv.reshape(n, CODE_DIM)
     out[:, F_BIAS] = cls_bias.reshape(n)
-    out[:, F_ACC] = 1.0 if acc_weight is None else torch.as_tensor(acc_weight, dtype=torch.float32, device=out.device)
-    out[:, F_CID] = torch.as_tensor(class_ids, dtype=torch.float32, device=out.device)
+    out[:, F_ACC] = 1.0 if acc_weight is None else torch.as_tensor(acc_weight, dtype=torch.float32, device=dev)
+    out[:, F_CID] = torch.as_tensor(class_ids, dtype=torch.float32, device=dev)
     out[:, F_VALID] = 1.0
+    if weight_norm is not None:
+        out[:, F_WNORM] = torch.as_tensor(weight_norm, dtype=torch.float32, device=dev).reshape(n)
+        out[:, F_HAS_WNORM] = 1.0
+    if names is not None:
+        out[:, F_NAME:] = _name_floats(names, n).to(dev)
     return out
 
 
-def gather_packed_codes(local: torch.Tensor) -> torch.Tensor:
-    """All ranks' (n_r, 260) rows concatenated in rank order (every rank gets the same result).
-    Blocks are padded to the max n_r so a single fixed-size all_gather suffices."""
-    world = get_world_size()
-    if world == 1:
-        return local
-    dev = local.device
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    nmax = max(int(c.item()) for c in counts)
-    padded = torch.zeros(max(nmax, 1), ROW, dtype=torch.float32, device=dev)
-    padded[: local.shape[0]] = local
-    blocks = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(blocks, padded)
-    return torch.cat([b[: int(c.item())] for b, c in zip(blocks, counts)], dim=0)
+def unpack_names(rows: torch.Tensor) -> List[str]:
+    """The 64-byte name fields of host rows -> strings (bit patterns survive the fp32 transport: copies only)."""
+    raw = rows[:, F_NAME:].contiguous().cpu().numpy().view(np.uint8).reshape(rows.shape[0], NAME_BYTES)
+    return [bytes(r).split(b"\0", 1)[0].decode("utf-8", "replace") for r in raw]
 
 
-def reduce_packed_codes(rows: torch.Tensor) -> torch.Tensor:
-    """reduce_class_code (sylph/modeling/code_generator/utils.py:397-427) on packed rows: sum the
-    (already len/total_len-weighted) chunk codes of each class id in order of first appearance,
-    divide by acc_weight when |1 - acc| > 1e-6; returned rows carry acc_weight = 1."""
+def pad_block(local: torch.Tensor, capacity: int) -> torch.Tensor:
+    """(n, ROW) -> (capacity, ROW), unused rows zero (valid = 0).  n <= capacity is a host-known invariant."""
+    assert local.shape[0] <= capacity, f"{local.shape[0]} rows do not fit the gather block of {capacity}"
+    if local.shape[0] == capacity:
+        return local.contiguous()
+    block = torch.zeros(capacity, ROW, dtype=torch.float32, device=local.device)
+    block[: local.shape[0]] = local
+    return block
+
+
+def gather_code_blocks(block: torch.Tensor) -> torch.Tensor:
+    """ONE collective: every rank's (capacity, ROW) block -> (world * capacity, ROW) in rank order on every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return block
+    world = get_world_size()  # a single-rank group still goes through the collective (RCCL init + call are exercised)
+    out = torch.empty(world * block.shape[0], ROW, dtype=torch.float32, device=block.device)
+    dist.all_gather_into_tensor(out, block.contiguous())
+    return out
+
+
+def gather_packed_codes(local: torch.Tensor, capacity: Optional[int] = None) -> torch.Tensor:
+    """All ranks' rows in rank order, padded: (world * capacity, ROW) with valid flags (no compaction: that would need a
+    host read-back; consumers select by the valid column).  capacity defaults to the local row count, which is only
+    correct when every rank holds the same number of rows."""
+    cap = int(capacity) if capacity is not None else max(int(local.shape[0]), 1)
+    return gather_code_blocks(pad_block(local, cap))
+
+
+def scatter_by_class_id(rows: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """format_class_codes_shared ordering (meta_learn_evaluation.py:71-103) without a host sync: out[c] <- the valid row
+    whose class id is c; invalid rows land in a scratch slot.  out[:, F_VALID] tells which classes arrived."""
+    cid = rows[:, F_CID].round().to(torch.int64)
+    idx = torch.where(rows[:, F_VALID] > 0, cid.clamp(0, num_classes - 1), torch.full_like(cid, num_classes))
+    out = torch.zeros(num_classes + 1, rows.shape[1], dtype=rows.dtype, device=rows.device)
+    out.index_copy_(0, idx, rows)
+    return out[:num_classes]
+
+
+def order_by_class_id(rows: torch.Tensor, num_classes: int, check: bool = True) -> torch.Tensor:
+    """scatter_by_class_id + (optionally, one host sync) the reference's completeness assertion."""
+    out = scatter_by_class_id(rows, num_classes)
+    if check:
+        got = int(out[:, F_VALID].sum().item())
+        assert got == num_classes, f"Got {got} class codes for prediction, but expect to be {num_classes}."
+    return out
+
+
+def reduce_packed_codes(rows: torch.Tensor, divide_by_acc: bool = True) -> torch.Tensor:
+    """reduce_class_code (sylph/modeling/code_generator/utils.py:397-427) on HOST rows (CPU tensors: the gloo tests and the
+    dict-level API); the device path is Engine.reduce_codes / sylph_reduce_codes with the same arithmetic.  Sums the
+    (already len/total_len-weighted) chunk codes of each class id in row order, first-appearance class order, divides by
+    acc_weight (accumulated in double, like the reference's Python floats) when |1 - acc| > 1e-6."""
+    rows = rows[rows[:, F_VALID] > 0]
     if rows.shape[0] == 0:
         return rows
     cids = rows[:, F_CID].round().to(torch.int64).tolist()
     order, index = [], {}
-    for i, c in enumerate(cids):
+    for c in cids:
         if c not in index:
             index[c] = len(order)
             order.append(c)
-    out = torch.zeros(len(order), ROW, dtype=torch.float32, device=rows.device)
+    out = torch.zeros(len(order), rows.shape[1], dtype=torch.float32, device=rows.device)
+    acc = [0.0] * len(order)
+    first = [-1] * len(order)
     for i, c in enumerate(cids):  # fixed order -> deterministic sums
-        out[index[c], : F_ACC + 1] += rows[i, : F_ACC + 1]
+        j = index[c]
+        out[j, : F_BIAS + 1] += rows[i, : F_BIAS + 1]
+        out[j, F_WNORM] += rows[i, F_WNORM]
+        out[j, F_HAS_WNORM] = max(float(out[j, F_HAS_WNORM]), float(rows[i, F_HAS_WNORM]))
+        acc[j] += float(rows[i, F_ACC])
+        if first[j] < 0:
+            first[j] = i
     for j, c in enumerate(order):
-        acc = float(out[j, F_ACC])
-        if abs(1.0 - acc) > 1e-6:
-            out[j, : F_BIAS + 1] /= acc
-        out[j, F_ACC] = 1.0
+        if divide_by_acc and abs(1.0 - acc[j]) > 1e-6:
+            a = torch.tensor(acc[j], dtype=torch.float32)
+            out[j, : F_BIAS + 1] /= a
+            out[j, F_WNORM] /= a
+        out[j, F_ACC] = 1.0 if divide_by_acc else acc[j]
         out[j, F_CID] = float(c)
         out[j, F_VALID] = 1.0
-    return out
-
-
-def order_by_class_id(rows: torch.Tensor, num_classes: int) -> torch.Tensor:
-    """format_class_codes_shared ordering (meta_learn_evaluation.py:71-103): row i <- class id i."""
-    cids = rows[:, F_CID].round().to(torch.int64)
-    assert sorted(cids.tolist()) == list(range(num_classes)), \
-        f"Got {rows.shape[0]} class codes for prediction, but expect to be {num_classes}."
-    out = torch.empty_like(rows)
-    out[cids] = rows
+        out[j, F_NAME:] = rows[first[j], F_NAME:]
     return out

@@ -346,11 +346,25 @@ class Engine:
         check(self.L.sylph_codegen(self._ctx, _ptr(bx), _ptr(out)), "codegen")
         return out
 
-    def normalize_codes(self, codes: torch.Tensor) -> torch.Tensor:
+    def normalize_codes(self, codes: torch.Tensor, weight_norm: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._stream()
         assert codes.is_cuda and codes.dtype == torch.float32 and codes.is_contiguous() and codes.shape[-1] == 257
-        check(self.L.sylph_normalize_codes(self._ctx, _ptr(codes), codes.shape[0]), "normalize_codes")
+        wn = None
+        if weight_norm is not None:
+            wn = weight_norm.to(self.device, torch.float32).reshape(-1).contiguous()
+            assert wn.numel() == codes.shape[0]
+        check(self.L.sylph_normalize_codes(self._ctx, _ptr(codes), codes.shape[0], _ptr(wn)), "normalize_codes")
         return codes
+
+    def reduce_codes(self, rows: torch.Tensor, num_classes: int, divide_by_acc: bool = True) -> torch.Tensor:
+        """Device-side reduce_class_code on packed rows (sylph_amd.distributed row layout) -> (num_classes, ROW), row c = class c.
+        divide_by_acc False: plain per-class accumulation (the per-rank step of the base-class path)."""
+        self._stream()
+        assert rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and rows.is_contiguous()
+        out = torch.empty(num_classes, rows.shape[1], device=self.device)
+        check(self.L.sylph_reduce_codes(self._ctx, _ptr(rows), rows.shape[0], rows.shape[1], _ptr(out), num_classes,
+                                        int(divide_by_acc)), "reduce_codes")
+        return out
 
     # ---- primitive entries (kernel parity tests) ------------------------------------------------------
     def conv2d(self, x, w, scale=None, shift=None, stride=1, pad=0, relu=False, residual=None):

@@ -104,26 +104,39 @@ def inference_on_support_set_dataset_base(model, data_loader, all_id_map=None, b
     """Base-class variant (meta_learn_evaluation.py:118-254): a class arrives in chunks of <= 10 shots
     carrying "len"/"total_len"; chunk codes are accumulated with weight len/total_len and the
     accumulated weight is kept in "acc_weight" for the cross-rank reduce."""
-    results, acc, names = [], {}, {}
+    from . import distributed as D
+    rows, names, engine = [], {}, getattr(model, "engine", None)
     with ExitStack() as stack:
         if isinstance(model, nn.Module):
             stack.enter_context(inference_context(model))
         stack.enter_context(torch.no_grad())
         for inputs in data_loader:
             assert len(inputs) == 1, "inputs' batch size is not 1"
-            code = model(inputs, run_type="meta_learn_test_support")
-            code = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in code.items()}
+            code = model(inputs, run_type="meta_learn_test_support")  # device tensors; nothing is read back per chunk
             cid = int(inputs[0]["support_set_target"])
             names[cid] = inputs[0]["class_name"]
             weight = float(inputs[0]["len"]) / inputs[0]["total_len"]
-            if cid in acc:
-                acc[cid]["cls_conv"] += code["cls_conv"] * weight
-                acc[cid]["cls_bias"] += code["cls_bias"] * weight
-                acc[cid]["acc_weight"] += weight
-            else:
-                acc[cid] = {"cls_conv": code["cls_conv"] * weight, "cls_bias": code["cls_bias"] * weight,
-                            "acc_weight": weight}
-    for cid, cc in acc.items():
+            wn = code["cls_weight_norm"].reshape(1) * weight if "cls_weight_norm" in code else None
+            rows.append(D.pack_codes(code["cls_conv"].reshape(1, 256) * weight, code["cls_bias"].reshape(1) * weight, [cid],
+                                     [weight], wn, [names[cid]]))
+    if not rows:
+        return []
+    packed = torch.cat(rows).contiguous()
+    ncls = max(names) + 1
+    # per-class accumulation of the weighted chunk codes in arrival order: ONE segmented reduce on the device
+    # (sylph_reduce_codes, divide_by_acc = 0); acc_weight keeps the accumulated weight for the cross-rank reduce
+    if engine is not None and packed.is_cuda:
+        red = engine.reduce_codes(packed, ncls, divide_by_acc=False)
+    else:
+        red = D.scatter_by_class_id(D.reduce_packed_codes(packed, divide_by_acc=False), ncls)
+    red = red.cpu()  # the only read-back of the loop
+    results = []
+    for cid in names:  # first-appearance order, as the reference's dict
+        r = red[cid]
+        cc = {"cls_conv": r[:256].reshape(1, 256, 1, 1).clone(), "cls_bias": r[256:257].reshape(1, 1, 1, 1).clone(),
+              "acc_weight": float(r[D.F_ACC])}
+        if float(r[D.F_HAS_WNORM]) > 0:
+            cc["cls_weight_norm"] = r[D.F_WNORM:D.F_WNORM + 1].reshape(1, 1, 1, 1).clone()
         results.append({"support_set_target": cid, "class_name": names[cid], "class_code": cc})
     return results
 

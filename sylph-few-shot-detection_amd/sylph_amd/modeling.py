@@ -192,18 +192,19 @@ class MetaOneStageDetector(nn.Module):
         assert codes is not None
         if len(codes) == 0:
             return codes
-        rows = []
+        rows, wns = [], []
         for code in codes:
             assert "class_code" in code, "class_code is not in code"
             assert "cls_conv" in code["class_code"], "class_conv is not in class_code"
-            if "cls_weight_norm" in code["class_code"]:
-                raise NotImplementedError("cls_weight_norm (SCALE_LAYER) is not supported")
             cc = code["class_code"]
             assert cc["cls_conv"].ndim == 4
             assert cc["cls_bias"].numel() == 1, "predicted bias should only have batch size 1"
             rows.append(torch.cat([cc["cls_conv"].reshape(-1).float(), cc["cls_bias"].reshape(-1).float()]))
+            if "cls_weight_norm" in cc:  # x cls_weight_norm after the L2 normalisation (code_generator.py:838-840)
+                wns.append(cc["cls_weight_norm"].reshape(-1).float())
+        assert len(wns) in (0, len(rows)), "cls_weight_norm must be present for all classes or none"
         packed = torch.stack(rows).to(self.device).contiguous()
-        out = self.engine.normalize_codes(packed)
+        out = self.engine.normalize_codes(packed, torch.cat(wns) if wns else None)
         for i, code in enumerate(codes):
             code["class_code"]["cls_conv"] = out[i, :256].reshape(1, 256, 1, 1)
             code["class_code"]["cls_bias"] = out[i, 256:257].reshape(1)

@@ -39,26 +39,56 @@ def create_cfg(default_cfg, config_file: Optional[str], overwrite_opts: Optional
     return cfg
 
 
-def reduce_class_code(out_codes: List[Dict]) -> List[Dict]:
-    """sylph/modeling/code_generator/utils.py:397-427 on the dict form (via the packed-row reducer)."""
+def _rows_from_codes(codes: List[Dict[str, Any]], device) -> torch.Tensor:
+    """list of {"support_set_target", "class_name", "class_code": {...}} -> packed rows (sylph_amd.distributed layout)."""
+    if not codes:
+        return torch.zeros(0, D.ROW, device=device)
+    conv = torch.cat([c["class_code"]["cls_conv"].reshape(1, 256).float() for c in codes]).to(device)
+    bias = torch.cat([c["class_code"]["cls_bias"].reshape(1).float() for c in codes]).to(device)
+    acc = [float(c["class_code"].get("acc_weight", 1.0)) for c in codes]
+    has_wn = all("cls_weight_norm" in c["class_code"] for c in codes)
+    wn = torch.cat([c["class_code"]["cls_weight_norm"].reshape(1).float() for c in codes]).to(device) if has_wn else None
+    return D.pack_codes(conv, bias, [int(c["support_set_target"]) for c in codes], acc, wn,
+                        [c.get("class_name") for c in codes])
+
+
+def _codes_from_rows(rows: torch.Tensor, keep_acc: bool, extras: Dict[int, Dict[str, Any]] = None) -> List[Dict[str, Any]]:
+    """Valid packed rows (host) -> the reference's list-of-dicts form, in row order."""
+    rows = rows.cpu()
+    rows = rows[rows[:, D.F_VALID] > 0]
+    names = D.unpack_names(rows)
+    out = []
+    for r, name in zip(rows, names):
+        cid = int(round(float(r[D.F_CID])))
+        cc = {"cls_conv": r[:256].reshape(1, 256, 1, 1).clone(), "cls_bias": r[256:257].reshape(1, 1, 1, 1).clone()}
+        if float(r[D.F_HAS_WNORM]) > 0:
+            cc["cls_weight_norm"] = r[D.F_WNORM:D.F_WNORM + 1].reshape(1, 1, 1, 1).clone()
+        if keep_acc:
+            cc["acc_weight"] = float(r[D.F_ACC])
+        rec = dict(extras.get(cid, {})) if extras else {}
+        rec.update({"support_set_target": cid, "class_name": name if name else rec.get("class_name"), "class_code": cc})
+        out.append(rec)
+    return out
+
+
+def reduce_class_code(out_codes: List[Dict], engine=None) -> List[Dict]:
+    """sylph/modeling/code_generator/utils.py:397-427 on the dict form.  With an Engine the sums run on the GPU
+    (sylph_reduce_codes, fixed row order); without one (CPU-only unit tests) on host rows with the same arithmetic."""
     if len(out_codes) == 0:
         return out_codes
     assert "class_code" in out_codes[0]
     others = {}
     for c in out_codes:
         others.setdefault(int(c["support_set_target"]), {k: v for k, v in c.items() if k != "class_code"})
-    conv = torch.cat([c["class_code"]["cls_conv"].reshape(1, 256).float() for c in out_codes])
-    bias = torch.cat([c["class_code"]["cls_bias"].reshape(1).float() for c in out_codes])
-    rows = D.pack_codes(conv, bias, [int(c["support_set_target"]) for c in out_codes],
-                        [float(c["class_code"]["acc_weight"]) for c in out_codes])
-    red = D.reduce_packed_codes(rows)
-    results = []
-    for r in red:
-        cid = int(round(float(r[D.F_CID])))
-        rec = dict(others[cid])
-        rec["class_code"] = {"cls_conv": r[:256].reshape(1, 256, 1, 1).clone(), "cls_bias": r[256:257].reshape(1, 1, 1, 1).clone()}
-        results.append(rec)
-    return results
+    if engine is not None:
+        rows = _rows_from_codes(out_codes, engine.device)
+        ncls = max(others) + 1
+        red = engine.reduce_codes(rows.contiguous(), ncls).cpu()
+        first = list(dict.fromkeys(int(c["support_set_target"]) for c in out_codes))  # the reference keeps first-appearance order
+        red = red[torch.tensor(first, dtype=torch.long)]
+    else:
+        red = D.reduce_packed_codes(_rows_from_codes(out_codes, torch.device("cpu")))
+    return _codes_from_rows(red, keep_acc=False, extras=others)
 
 
 class MetaFCOSRunner:
@@ -79,49 +109,42 @@ class MetaFCOSRunner:
         return model
 
     @classmethod
-    def _gather_class_code(cls, sub_class_codes: List[Dict[str, Any]], reduce: bool = False) -> List[Dict[str, Any]]:
-        """meta_fcos_runner.py:381-439.  Same result as all_gather_object + rank-order flatten, but the
-        codes travel as ONE dense fp32 block per rank (sylph_amd.distributed) over RCCL/gloo; class names
-        (host metadata) ride along through a small object gather only when world_size > 1."""
+    def _gather_class_code(cls, sub_class_codes: List[Dict[str, Any]], reduce: bool = False, capacity: Optional[int] = None,
+                           engine=None) -> List[Dict[str, Any]]:
+        """meta_fcos_runner.py:381-439.  Same result as all_gather_object + rank-order flatten, but everything a code
+        carries (weights, bias, accumulated weight, class id, weight norm, class name) travels in ONE dense fp32 block
+        per rank through ONE all_gather_into_tensor over RCCL / gloo (sylph_amd.distributed): no pickle, no count
+        exchange.  `capacity` = rows every rank reserves (default: the InferenceSampler shard size is not known here, so
+        the maximum over ranks is agreed on by one scalar all_reduce; callers that know it pass it and skip that)."""
         world = D.get_world_size()
         if world > 1:
             import torch.distributed as dist
             dev = sub_class_codes[0]["class_code"]["cls_conv"].device if sub_class_codes else torch.device("cpu")
             if dist.get_backend() == "nccl":
                 dev = torch.device("cuda", torch.cuda.current_device())
-            if sub_class_codes:
-                conv = torch.cat([c["class_code"]["cls_conv"].reshape(1, 256).float() for c in sub_class_codes]).to(dev)
-                bias = torch.cat([c["class_code"]["cls_bias"].reshape(1).float() for c in sub_class_codes]).to(dev)
-                acc = [float(c["class_code"].get("acc_weight", 1.0)) for c in sub_class_codes]
-                local = D.pack_codes(conv, bias, [int(c["support_set_target"]) for c in sub_class_codes], acc)
-            else:
-                local = torch.zeros(0, D.ROW, device=dev)
-            rows = D.gather_packed_codes(local).cpu()
-            names = [None] * world
-            dist.all_gather_object(names, [(int(c["support_set_target"]), c.get("class_name")) for c in sub_class_codes])
-            flat_names = [n for sub in names for n in sub]
-            has_acc = any("acc_weight" in c["class_code"] for c in sub_class_codes) or reduce
-            out_codes = []
-            for r, (cid, name) in zip(rows, flat_names):
-                cc = {"cls_conv": r[:256].reshape(1, 256, 1, 1).clone(), "cls_bias": r[256:257].reshape(1, 1, 1, 1).clone()}
-                if has_acc:
-                    cc["acc_weight"] = float(r[D.F_ACC])
-                out_codes.append({"support_set_target": cid, "class_name": name, "class_code": cc})
+            local = _rows_from_codes(sub_class_codes, dev)
+            if capacity is None:
+                cap = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+                dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+                capacity = max(int(cap.item()), 1)
+            rows = D.gather_packed_codes(local, capacity)
+            has_acc = reduce or any("acc_weight" in c["class_code"] for c in sub_class_codes)
+            out_codes = _codes_from_rows(rows, keep_acc=has_acc)
         else:
             out_codes = sub_class_codes
         if not reduce:
             return out_codes
-        return reduce_class_code(out_codes)
+        return reduce_class_code(out_codes, engine=engine)
 
     def _do_test_meta_learning(self, cfg, model, support_loader, query_loader, evaluator=None, base_support_loader=None,
                                output_folder: Optional[str] = None, num_classes: Optional[int] = None):
         """Control flow of meta_fcos_runner.py:451-560 for ONE dataset/seed: support codes -> gather ->
         (base-class reduce + replace) -> normalise -> format -> query loop."""
         sub = inference_on_support_set_dataset(model, support_loader, output_dir=output_folder)
-        codes = self._gather_class_code(sub)
+        codes = self._gather_class_code(sub, capacity=D.shard_capacity(num_classes) if num_classes else None)
         if base_support_loader is not None:
             base_sub = inference_on_support_set_dataset_base(model, base_support_loader)
-            base = self._gather_class_code(base_sub, reduce=True)
+            base = self._gather_class_code(base_sub, reduce=True, engine=getattr(model, "engine", None))
             by_cid = {int(c["support_set_target"]): c for c in base}
             codes = [dict(c, class_code=by_cid[int(c["support_set_target"])]["class_code"])
                      if int(c["support_set_target"]) in by_cid else c for c in codes]

@@ -1,0 +1,128 @@
+"""GPU tests of the class-code exchange: device-side segmented reduce (sylph_reduce_codes) against the reference golden,
+the base-class "use all ground truths" episode against the oracle, and the RCCL path itself (backend "nccl",
+world size 1: process-group init + the one all_gather_into_tensor run on the real GPU)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _chunks(g, with_wn=True):
+    chunks = []
+    for i in range(5):
+        keys = ("cls_conv", "cls_bias", "cls_weight_norm") if with_wn else ("cls_conv", "cls_bias")
+        cc = {k: torch.as_tensor(g[f"chunk{i}_{k}"]) for k in keys}
+        cc["acc_weight"] = float(g[f"chunk{i}_acc_weight"])
+        chunks.append({"support_set_target": int(g[f"chunk{i}_cid"]), "class_name": f"k{int(g[f'chunk{i}_cid'])}", "class_code": cc})
+    return chunks
+
+
+def test_reduce_codes_device_matches_reference_golden(golden_dir):
+    """reduce_class_code of the reference (utils.py:397-427) incl. cls_weight_norm: class 0 weights sum to 1 (no division),
+    class 1 to 0.7 (divided by the accumulated weight)."""
+    from sylph_amd import distributed as D
+    from sylph_amd.engine import Engine
+    from sylph_amd.runner import MetaFCOSRunner, _rows_from_codes
+    g = np.load(os.path.join(golden_dir, "g5_reduce_condblock.npz"))
+    eng = Engine(None, dtype="f32")
+    rows = _rows_from_codes(_chunks(g), eng.device)
+    red = eng.reduce_codes(rows.contiguous(), 3).cpu()
+    assert red[:, D.F_VALID].tolist() == [1.0, 1.0, 0.0]
+    for cid in (0, 1):
+        np.testing.assert_allclose(red[cid, :256].numpy(), g[f"reduced{cid}_cls_conv"].reshape(-1), atol=1e-6)
+        np.testing.assert_allclose(red[cid, D.F_BIAS].item(), g[f"reduced{cid}_cls_bias"].reshape(-1)[0], atol=1e-6)
+        np.testing.assert_allclose(red[cid, D.F_WNORM].item(), g[f"reduced{cid}_cls_weight_norm"].reshape(-1)[0], atol=1e-6)
+    assert D.unpack_names(red[:2]) == ["k0", "k1"]
+    # the runner entry with an engine takes the same device path and returns the reference's dict form
+    out = MetaFCOSRunner._gather_class_code(_chunks(g), reduce=True, engine=eng)
+    assert [r["support_set_target"] for r in out] == [0, 1] and "acc_weight" not in out[0]["class_code"]
+    np.testing.assert_allclose(out[1]["class_code"]["cls_conv"].numpy(), g["reduced1_cls_conv"], atol=1e-6)
+    np.testing.assert_allclose(out[1]["class_code"]["cls_weight_norm"].numpy(), g["reduced1_cls_weight_norm"], atol=1e-6)
+    # plain accumulation (per-rank step): sums only, accumulated weight kept
+    acc = eng.reduce_codes(rows.contiguous(), 2, divide_by_acc=False).cpu()
+    assert abs(acc[1, D.F_ACC].item() - 0.7) < 1e-6
+    np.testing.assert_allclose(acc[1, :256].numpy() / 0.7, g["reduced1_cls_conv"].reshape(-1), atol=1e-5)
+
+
+def test_base_class_support_path_matches_oracle():
+    """inference_on_support_set_dataset_base + reduce + replace (meta_learn_evaluation.py:118-254) driven through the
+    runner with a base_support_loader: class 0 has 13 shots (chunks 10 + 3), class 1 has 4; both replace the few-shot codes."""
+    from oracle import codegen as CG, episode as E
+    from sylph_amd import synthetic as W
+    from sylph_amd.data import SyntheticBaseSupportLoader, SyntheticQueryLoader, SyntheticSupportSetLoader
+    from sylph_amd.runner import MetaFCOSRunner, create_cfg
+    runner = MetaFCOSRunner()
+    cfg = create_cfg(runner.get_default_cfg(), "sylph://COCO-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml")
+    sd = W.synthetic_state_dict(0, depth=50)
+    model = runner.build_model(cfg, dtype="f32")
+    model.load_state_dict(sd)
+    model.eval()
+    sup = SyntheticSupportSetLoader(3, 1, 96, 128, seed=3)
+    base = SyntheticBaseSupportLoader([13, 4], 96, 128, chunk=10, seed=9)
+    assert len(base) == 3
+    qry = SyntheticQueryLoader(1, 96, 128, batch_size=1, seed=4)
+    _, codes = runner._do_test_meta_learning(cfg, model, sup, qry, None, base_support_loader=base, num_classes=3)
+    # oracle: weighted sum of the chunk codes per base class, then normalisation
+    acc = {}
+    for item in base:
+        it = item[0]
+        imgs = [r["image"].cpu() for r in it["support_set"]]
+        boxes = torch.cat([r["instances"].gt_boxes.tensor for r in it["support_set"]])
+        c = E.forward_class_code(imgs, boxes, sd)
+        wgt = it["len"] / it["total_len"]
+        cid = int(it["support_set_target"])
+        a = acc.setdefault(cid, {"cls_conv": 0, "cls_bias": 0})
+        a["cls_conv"] = a["cls_conv"] + c["cls_conv"] * wgt
+        a["cls_bias"] = a["cls_bias"] + c["cls_bias"] * wgt
+    recs = [{"support_set_target": torch.tensor(k), "class_name": str(k), "class_code": v} for k, v in acc.items()]
+    ref = CG.forward_normalize_code(recs, sd)
+    for r in ref:
+        k = int(r["support_set_target"])
+        np.testing.assert_allclose(codes["cls_conv"][k].reshape(-1).cpu().numpy(), r["class_code"]["cls_conv"].reshape(-1).numpy(), atol=1e-3)
+        np.testing.assert_allclose(codes["cls_bias"][k].item(), r["class_code"]["cls_bias"].item(), atol=1e-3)
+    assert codes["cls_conv"].shape == (3, 256, 1, 1)
+
+
+_NCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "sylph-few-shot-detection_amd"))
+import torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from sylph_amd import distributed as D
+from sylph_amd.engine import Engine
+g = torch.Generator().manual_seed(3)
+conv, bias = torch.randn(5, 256, generator=g).cuda(), torch.randn(5, generator=g).cuda()
+local = D.pack_codes(conv, bias, [4, 0, 2, 4, 1], acc_weight=[0.5, 1.0, 1.0, 0.25, 1.0], names=["e", "a", "c", "e", "b"])
+rows = D.gather_packed_codes(local, capacity=8)          # RCCL all_gather_into_tensor on the GPU
+assert rows.shape == (8, D.ROW) and rows.is_cuda
+torch.cuda.synchronize()
+assert torch.equal(rows[:5], local) and float(rows[5:, D.F_VALID].abs().sum()) == 0.0
+eng = Engine(None, dtype="f32")
+red = eng.reduce_codes(rows.contiguous(), 5).cpu()
+host = D.scatter_by_class_id(D.reduce_packed_codes(rows.cpu()), 5)
+ok = host[:, D.F_VALID] > 0
+assert ok.tolist() == [True, True, True, False, True] and torch.equal(red[:, D.F_VALID] > 0, ok)
+assert torch.allclose(red[ok][:, :262], host[ok][:, :262], atol=1e-6), (red[ok][:, :262] - host[ok][:, :262]).abs().max()
+assert D.unpack_names(red) == ["a", "b", "c", "", "e"]
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_WORLD1_OK")
+"""
+
+
+def test_rccl_backend_world1_gather_reduce():
+    """Nothing else in the suite touches RCCL (the driver has no multi-GPU node): initialise backend "nccl" with one rank
+    and run the episode's single collective + the device reduce on the real GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_SCRIPT % {"root": ROOT}], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

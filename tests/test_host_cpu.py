@@ -117,7 +117,7 @@ def test_structures():
 def _chunks(g):
     chunks = []
     for i in range(5):
-        cc = {k: torch.as_tensor(g[f"chunk{i}_{k}"]) for k in ("cls_conv", "cls_bias")}
+        cc = {k: torch.as_tensor(g[f"chunk{i}_{k}"]) for k in ("cls_conv", "cls_bias", "cls_weight_norm")}
         cc["acc_weight"] = float(g[f"chunk{i}_acc_weight"])
         chunks.append({"support_set_target": int(g[f"chunk{i}_cid"]), "class_name": f"k{int(g[f'chunk{i}_cid'])}",
                        "class_code": cc})
@@ -134,6 +134,7 @@ def test_reduce_class_code_matches_reference_golden(golden_dir):
         assert "acc_weight" not in r["class_code"]
         np.testing.assert_allclose(r["class_code"]["cls_conv"].numpy(), g[f"reduced{cid}_cls_conv"], atol=1e-6)
         np.testing.assert_allclose(r["class_code"]["cls_bias"].numpy(), g[f"reduced{cid}_cls_bias"], atol=1e-6)
+        np.testing.assert_allclose(r["class_code"]["cls_weight_norm"].numpy(), g[f"reduced{cid}_cls_weight_norm"], atol=1e-6)
 
 
 def test_format_class_codes_matches_reference_golden(golden_dir):
@@ -189,8 +190,9 @@ def _worker(rank, world, port, golden_dir, out):
         gathered = MetaFCOSRunner._gather_class_code(mine)
         reduced = MetaFCOSRunner._gather_class_code(mine, reduce=True)
         # dense-block gather with an empty rank
-        local = D.pack_codes(torch.randn(3, 256), torch.randn(3), [4, 5, 6]) if rank == 1 else torch.zeros(0, D.ROW)
-        rows = D.gather_packed_codes(local)
+        local = (D.pack_codes(torch.randn(3, 256), torch.randn(3), [4, 5, 6], names=["cat", "d\u00f6g", "x" * 80])
+                 if rank == 1 else torch.zeros(0, D.ROW))
+        rows = D.gather_packed_codes(local, capacity=4)  # ONE all_gather_into_tensor of equal-size blocks
         if rank == 0:
             torch.save({"gathered": gathered, "reduced": reduced, "rows": rows}, out)
     finally:
@@ -214,7 +216,12 @@ def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
     for r in res["reduced"]:
         cid = r["support_set_target"]
         np.testing.assert_allclose(r["class_code"]["cls_conv"].numpy(), g[f"reduced{cid}_cls_conv"], atol=1e-6)
-    assert res["rows"].shape == (3, D.ROW) and res["rows"][:, D.F_CID].tolist() == [4.0, 5.0, 6.0]
+    rows = res["rows"]
+    assert rows.shape == (8, D.ROW) and rows[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1, 1, 0]
+    assert rows[4:7, D.F_CID].tolist() == [4.0, 5.0, 6.0]
+    assert D.unpack_names(rows[4:7]) == ["cat", "d\u00f6g", "x" * 64]
+    by_id = D.scatter_by_class_id(rows, 8)
+    assert by_id[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1, 1, 0] and torch.equal(by_id[5], rows[5])
 
 
 def test_detections_to_coco_rows_batches_one_copy():
