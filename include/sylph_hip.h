@@ -87,6 +87,16 @@ int sylph_finalize_weights(sylph_ctx* ctx);
 int sylph_preprocess(sylph_ctx* ctx, int B, const float* const* images_dev, const int* heights, const int* widths,
                      int* padded_h, int* padded_w);
 
+/* Fused input pipeline: what SylphPredictor does on the host before the model call
+ * (sylph/predictor.py:117-120,259-269: detectron2 ResizeShortestEdge -> ResizeTransform = PIL BILINEAR on the uint8 image,
+ * RGB->BGR when INPUT.FORMAT is RGB, float CHW tensor) fused with convert_batched_inputs_to_image_list.  images_dev[b]:
+ * device pointer to a (h, w, 3) uint8 HWC image (e.g. copied from a pinned host batch); new_heights/new_widths: the resize
+ * targets.  Pillow's fixed-point two-pass resampling is reproduced bit for bit.  Makes the padded batch current. */
+int sylph_preprocess_u8(sylph_ctx* ctx, int B, const unsigned char* const* images_dev, const int* heights, const int* widths,
+                        const int* new_heights, const int* new_widths, int rgb_input, int* padded_h, int* padded_w);
+/* Boundary/test entry: the normalised, padded network input of the current batch as (B,3,H,W) fp32 NCHW. */
+int sylph_export_input(sylph_ctx* ctx, float* out_nchw_dev);
+
 /* self.backbone(images.tensor) (meta_one_stage_detector.py:181,273): ResNet-FPN on the current batch. */
 int sylph_backbone_fpn(sylph_ctx* ctx);
 

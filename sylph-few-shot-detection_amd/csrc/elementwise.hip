@@ -50,6 +50,82 @@ int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused input pipeline: uint8 HWC image -> ResizeShortestEdge target size with PIL's BILINEAR
+// resampling (what detectron2's ResizeTransform applies to uint8 images: sylph/predictor.py:117-120,259-269) -> optional
+// RGB->BGR -> (x - mean) / std -> zero pad -> [B][H][W][4] in the compute dtype, in ONE pass.
+// Pillow semantics (Resample.c, 8 bits per channel), reproduced bit for bit: two separable passes, horizontal first, each
+// with a triangle filter whose support is scaled by the down-sampling factor (antialiasing), coefficients normalised per
+// output pixel and rounded to 22-bit fixed point, the horizontal result ROUNDED TO uint8 before the vertical pass.
+// The coefficient tables are built on the host in double exactly as Pillow does (sylph_api.hip pil_bilinear_coeffs); this
+// kernel does the integer arithmetic: out = clip8((2^21 + sum_j kv[j] * clip8((2^21 + sum_i kh[i] * px) >> 22)) >> 22).
+__device__ __forceinline__ int clip8(int v) {
+  v >>= 22;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+template <typename T>
+__global__ void resize_preprocess_kernel(const ResizeDesc* descs, const int* __restrict__ tab, T* out, int H, int W, float m0,
+                                         float m1, float m2, float is0, float is1, float is2, int rgb_input) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= W) return;
+  const ResizeDesc d = descs[b];
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+  if (y < d.new_h && x < d.new_w) {
+    const int xmin = tab[d.hb_off + 2 * x], xn = tab[d.hb_off + 2 * x + 1];
+    const int ymin = tab[d.vb_off + 2 * y], yn = tab[d.vb_off + 2 * y + 1];
+    const int* kh = tab + d.hk_off + x * d.ksh;
+    const int* kv = tab + d.vk_off + y * d.ksv;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int j = 0; j < yn; ++j) {
+      const unsigned char* row = d.src + ((size_t)(ymin + j) * d.w + xmin) * 3;
+      int h0 = 1 << 21, h1 = 1 << 21, h2 = 1 << 21;
+      for (int i = 0; i < xn; ++i) {
+        const int k = kh[i];
+        h0 += row[3 * i] * k; h1 += row[3 * i + 1] * k; h2 += row[3 * i + 2] * k;
+      }
+      const int w = kv[j];
+      a0 += clip8(h0) * w; a1 += clip8(h1) * w; a2 += clip8(h2) * w;
+    }
+    int c0 = clip8(a0), c1 = clip8(a1), c2 = clip8(a2);
+    if (rgb_input) { const int t = c0; c0 = c2; c2 = t; }  // the model works in BGR (cfg.INPUT.FORMAT, predictor.py:259-262)
+    v0 = ((float)c0 - m0) * is0;
+    v1 = ((float)c1 - m1) * is1;
+    v2 = ((float)c2 - m2) * is2;
+  }
+  T* o = out + (((size_t)b * H + y) * W + x) * 4;
+  o[0] = Cvt<T>::from_f(v0); o[1] = Cvt<T>::from_f(v1); o[2] = Cvt<T>::from_f(v2); o[3] = Cvt<T>::from_f(0.f);
+}
+
+int launch_resize_preprocess(DType dt, const ResizeDesc* descs_dev, const int* tab_dev, void* out, int B, int H, int W,
+                             const float* mean, const float* stdv, int rgb_input, hipStream_t s) {
+  dim3 grid((W + 127) / 128, H, B), block(128);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(resize_preprocess_kernel<bf16_t>, grid, block, 0, s, descs_dev, tab_dev, (bf16_t*)out, H, W, mean[0], mean[1],
+                       mean[2], 1.f / stdv[0], 1.f / stdv[1], 1.f / stdv[2], rgb_input);
+  else
+    hipLaunchKernelGGL(resize_preprocess_kernel<float>, grid, block, 0, s, descs_dev, tab_dev, (float*)out, H, W, mean[0], mean[1],
+                       mean[2], 1.f / stdv[0], 1.f / stdv[1], 1.f / stdv[2], rgb_input);
+  return (int)hipGetLastError();
+}
+
+// [B][H][W][4] compute dtype -> (B,3,H,W) fp32 NCHW (test boundary: the preprocessed network input)
+template <typename T>
+__global__ void export_input_kernel(const T* __restrict__ x, float* __restrict__ out, int H, int W) {
+  const int b = blockIdx.z, y = blockIdx.y, xx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xx >= W) return;
+  const T* p = x + (((size_t)b * H + y) * W + xx) * 4;
+  for (int c = 0; c < 3; ++c) out[(((size_t)b * 3 + c) * H + y) * W + xx] = Cvt<T>::to_f(p[c]);
+}
+
+int launch_export_input(DType dt, const void* x, float* out, int B, int H, int W, hipStream_t s) {
+  dim3 grid((W + 127) / 128, H, B), block(128);
+  if (dt == DT_BF16) hipLaunchKernelGGL(export_input_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, out, H, W);
+  else hipLaunchKernelGGL(export_input_kernel<float>, grid, block, 0, s, (const float*)x, out, H, W);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // max-pool 3x3 stride 2 pad 1 over [B][H][W][C]; one thread = 8 channels of one output position.
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int Ho,

@@ -6,6 +6,8 @@ namespace sylph {
 
 struct ImageDesc { const float* ptr; int h, w; };   // one (3,h,w) fp32 plane-major image on device
 struct RowSeg { int row0, nrows; };                 // a run of rows (one GroupNorm sample)
+// one uint8 HWC image of the fused resize input pipeline: source, target size, offsets of its tables in the int table buffer
+struct ResizeDesc { const unsigned char* src; int h, w, new_h, new_w; int hb_off, hk_off, vb_off, vk_off, ksh, ksv; };
 
 constexpr int GN_ROWS_PER_CHUNK = 256;
 // a GroupNorm sample (= conv segment) whose statistics were left by the conv epilogue as per-M-tile partials
@@ -62,6 +64,9 @@ struct ImageOut { float sx, sy, out_w, out_h; };  // postprocess scale + clip bo
 // elementwise.hip
 int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int H, int W, const float* mean,
                       const float* stdv, hipStream_t s);
+int launch_resize_preprocess(DType dt, const ResizeDesc* descs_dev, const int* tab_dev, void* out, int B, int H, int W,
+                             const float* mean, const float* stdv, int rgb_input, hipStream_t s);
+int launch_export_input(DType dt, const void* x, float* out, int B, int H, int W, hipStream_t s);
 int launch_maxpool(DType dt, const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t s);
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s);

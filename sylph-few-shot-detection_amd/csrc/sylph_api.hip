@@ -69,6 +69,50 @@ struct GNLayer {
 
 struct Plan;
 
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (libImaging/Resample.c), in double like the
+// original: per output index the first input index, the tap count and `ksize` 22-bit fixed-point weights.
+struct PilCoeffs {
+  int ksize = 0;
+  std::vector<int> bounds;  // [out][2] = (first, count)
+  std::vector<int> kk;      // [out][ksize]
+};
+static std::shared_ptr<PilCoeffs> pil_bilinear_coeffs(int in_size, int out_size) {
+  auto pc = std::make_shared<PilCoeffs>();
+  const double scale = (double)in_size / (double)out_size;
+  double filterscale = scale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = 1.0 * filterscale;  // bilinear filter support = 1
+  const int ksize = (int)ceil(support) * 2 + 1;
+  pc->ksize = ksize;
+  pc->bounds.assign((size_t)out_size * 2, 0);
+  pc->kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> k((size_t)ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double a = (x + xmin - center + 0.5) * ss;
+      if (a < 0.0) a = -a;
+      const double w = a < 1.0 ? 1.0 - a : 0.0;
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x) {
+      if (ww != 0.0) k[x] /= ww;
+      pc->kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (double)(1 << 22)) : (int)(0.5 + k[x] * (double)(1 << 22));
+    }
+    pc->bounds[2 * xx] = xmin;
+    pc->bounds[2 * xx + 1] = xmax;
+  }
+  return pc;
+}
+
 struct sylph_ctx {
   int device = 0;
   DType dt = DT_BF16;
@@ -109,6 +153,7 @@ struct sylph_ctx {
   bool has_backbone = false, has_head = false, has_codegen = false, has_roienc = false;
   // plans
   std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
+  std::map<std::pair<int, int>, std::shared_ptr<struct PilCoeffs>> pil_cache;  // (in size, out size) -> resampling tables
   std::map<const void*, void*> hp_weights;  // conv_hpipe.hip re-packed copies of 3x3 weights, keyed by the igemm-layout pointer
   Plan* cur = nullptr;
   void* zeros = nullptr;  // 256 B of zeros (conv out-of-image taps)
@@ -151,6 +196,12 @@ struct Plan {
   bool backbone_built = false, head_built = false, support_built = false;
   ImageDesc* img_desc_dev = nullptr;
   ImageDesc* img_desc_host = nullptr;
+  hipEvent_t img_desc_ev = nullptr;  // recorded after the H2D copy of img_desc_host / rz_host (guards their reuse)
+  // fused resize input pipeline: per-image descriptors + PIL coefficient tables (pinned host staging, device copy)
+  ResizeDesc* rz_desc_dev = nullptr;
+  char* rz_host = nullptr;  // [B descs][int table]
+  int* rz_tab_dev = nullptr;
+  size_t rz_tab_cap = 0;
   // head
   void *tA = nullptr, *tB = nullptr, *tC = nullptr, *tD = nullptr;
   void* cls_feat = nullptr;  // output of the cls tower (input of the class-conditional conv)
@@ -1119,6 +1170,8 @@ void sylph_ctx_destroy(sylph_ctx* c) {
     if (kv.second->img_desc_host) (void)hipHostFree(kv.second->img_desc_host);
     if (kv.second->img_out_host) (void)hipHostFree(kv.second->img_out_host);
     if (kv.second->img_out_ev) (void)hipEventDestroy(kv.second->img_out_ev);
+    if (kv.second->img_desc_ev) (void)hipEventDestroy(kv.second->img_desc_ev);
+    if (kv.second->rz_host) (void)hipHostFree(kv.second->rz_host);
   }
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
@@ -1417,18 +1470,93 @@ int sylph_preprocess(sylph_ctx* c, int B, const float* const* images, const int*
   if (d > 1) { mh = (mh + d - 1) / d * d; mw = (mw + d - 1) / d * d; }
   Plan* P = get_plan(c, B, mh, mw);
   RET(build_backbone(c, P));
-  // the previous batch's copy of the descriptor table must have been consumed
-  HIPCHK(hipStreamSynchronize(c->stream));
+  // the previous batch's H2D copy of the pinned descriptor table must have been consumed: wait for THAT copy only
+  // (an event), not for the stream: the host stays free to enqueue the next step behind the running one
+  if (P->img_desc_ev) HIPCHK(hipEventSynchronize(P->img_desc_ev));
+  else HIPCHK(hipEventCreateWithFlags(&P->img_desc_ev, hipEventDisableTiming));
   for (int b = 0; b < B; ++b) {
     P->img_desc_host[b].ptr = images[b]; P->img_desc_host[b].h = hs[b]; P->img_desc_host[b].w = ws[b];
     P->img_h[b] = hs[b]; P->img_w[b] = ws[b];
   }
   HIPCHK(hipMemcpyAsync(P->img_desc_dev, P->img_desc_host, sizeof(ImageDesc) * B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(P->img_desc_ev, c->stream));
   KCHK(launch_preprocess(c->dt, P->img_desc_dev, P->x0, B, mh, mw, c->cfg.pixel_mean, c->cfg.pixel_std, c->stream),
        "preprocess");
   c->cur = P;
   if (ph) *ph = mh;
   if (pw) *pw = mw;
+  return 0;
+}
+
+int sylph_preprocess_u8(sylph_ctx* c, int B, const unsigned char* const* images, const int* hs, const int* ws, const int* nhs,
+                        const int* nws, int rgb_input, int* ph, int* pw) {
+  if (!c->finalized) return fail("weights not finalized");
+  if (B <= 0) return fail("empty batch");
+  HIPCHK(hipSetDevice(c->device));
+  int mh = 0, mw = 0;
+  for (int b = 0; b < B; ++b) {
+    if (hs[b] <= 0 || ws[b] <= 0 || nhs[b] <= 0 || nws[b] <= 0) return fail("sylph_preprocess_u8: bad image size");
+    mh = nhs[b] > mh ? nhs[b] : mh; mw = nws[b] > mw ? nws[b] : mw;
+  }
+  const int d = c->cfg.size_divisibility;
+  if (d > 1) { mh = (mh + d - 1) / d * d; mw = (mw + d - 1) / d * d; }
+  Plan* P = get_plan(c, B, mh, mw);
+  RET(build_backbone(c, P));
+  // resampling tables of every image (cached per (in, out) size pair), laid out back to back
+  std::vector<std::shared_ptr<PilCoeffs>> hc((size_t)B), vc((size_t)B);
+  size_t nint = 0;
+  for (int b = 0; b < B; ++b) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const std::pair<int, int> key = pass == 0 ? std::make_pair(ws[b], nws[b]) : std::make_pair(hs[b], nhs[b]);
+      auto it = c->pil_cache.find(key);
+      if (it == c->pil_cache.end()) {
+        if (c->pil_cache.size() > 256) c->pil_cache.clear();
+        it = c->pil_cache.emplace(key, pil_bilinear_coeffs(key.first, key.second)).first;
+      }
+      (pass == 0 ? hc : vc)[b] = it->second;
+      nint += it->second->bounds.size() + it->second->kk.size();
+    }
+  }
+  if (P->img_desc_ev) HIPCHK(hipEventSynchronize(P->img_desc_ev));
+  else HIPCHK(hipEventCreateWithFlags(&P->img_desc_ev, hipEventDisableTiming));
+  const size_t need = sizeof(ResizeDesc) * B + nint * sizeof(int);
+  if (need > P->rz_tab_cap) {
+    if (P->rz_host) (void)hipHostFree(P->rz_host);
+    if (P->rz_desc_dev) c->dfree(P->rz_desc_dev);
+    P->rz_host = nullptr; P->rz_desc_dev = nullptr; P->rz_tab_cap = 0;
+    const size_t cap = need + need / 2;
+    HIPCHK(hipHostMalloc((void**)&P->rz_host, cap));
+    RET(c->dalloc((void**)&P->rz_desc_dev, cap));
+    P->rz_tab_cap = cap;
+  }
+  ResizeDesc* dh = reinterpret_cast<ResizeDesc*>(P->rz_host);
+  int* th = reinterpret_cast<int*>(P->rz_host + sizeof(ResizeDesc) * B);
+  size_t off = 0;
+  for (int b = 0; b < B; ++b) {
+    ResizeDesc& r = dh[b];
+    r.src = images[b]; r.h = hs[b]; r.w = ws[b]; r.new_h = nhs[b]; r.new_w = nws[b];
+    r.ksh = hc[b]->ksize; r.ksv = vc[b]->ksize;
+    r.hb_off = (int)off; memcpy(th + off, hc[b]->bounds.data(), hc[b]->bounds.size() * sizeof(int)); off += hc[b]->bounds.size();
+    r.hk_off = (int)off; memcpy(th + off, hc[b]->kk.data(), hc[b]->kk.size() * sizeof(int)); off += hc[b]->kk.size();
+    r.vb_off = (int)off; memcpy(th + off, vc[b]->bounds.data(), vc[b]->bounds.size() * sizeof(int)); off += vc[b]->bounds.size();
+    r.vk_off = (int)off; memcpy(th + off, vc[b]->kk.data(), vc[b]->kk.size() * sizeof(int)); off += vc[b]->kk.size();
+    P->img_h[b] = nhs[b]; P->img_w[b] = nws[b];
+  }
+  HIPCHK(hipMemcpyAsync(P->rz_desc_dev, P->rz_host, need, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(P->img_desc_ev, c->stream));
+  const int* tab_dev = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P->rz_desc_dev) + sizeof(ResizeDesc) * B);
+  KCHK(launch_resize_preprocess(c->dt, P->rz_desc_dev, tab_dev, P->x0, B, mh, mw, c->cfg.pixel_mean, c->cfg.pixel_std, rgb_input,
+                                c->stream), "resize_preprocess");
+  c->cur = P;
+  if (ph) *ph = mh;
+  if (pw) *pw = mw;
+  return 0;
+}
+
+int sylph_export_input(sylph_ctx* c, float* out) {
+  Plan* P = c->cur;
+  if (!P || !P->x0) return fail("sylph_preprocess must be called first");
+  KCHK(launch_export_input(c->dt, P->x0, out, P->B, P->H, P->W, c->stream), "export_input");
   return 0;
 }
 

@@ -44,6 +44,9 @@ PROTOTYPES = {
     "sylph_finalize_weights": (c_int, [c_void_p]),
     "sylph_preprocess": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_int),
                                  POINTER(c_int), POINTER(c_int)]),
+    "sylph_preprocess_u8": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                    POINTER(c_int), c_int, POINTER(c_int), POINTER(c_int)]),
+    "sylph_export_input": (c_int, [c_void_p, c_void_p]),
     "sylph_backbone_fpn": (c_int, [c_void_p]),
     "sylph_import_pyramid": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                                      POINTER(c_void_p)]),

@@ -183,6 +183,30 @@ class Engine:
         self._batch = (B, ph.value, pw.value, [(int(im.shape[1]), int(im.shape[2])) for im in imgs])
         return ph.value, pw.value
 
+    def preprocess_u8(self, images: List[torch.Tensor], new_sizes: List[Tuple[int, int]], rgb_input: bool = False) -> Tuple[int, int]:
+        """Fused input pipeline: (h, w, 3) uint8 HWC images (device, or pinned host: copied asynchronously here) ->
+        PIL-exact BILINEAR resize to new_sizes -> BGR -> normalise -> pad; one kernel (sylph_preprocess_u8)."""
+        self._stream()
+        imgs = [im.to(self.device, non_blocking=True).contiguous() for im in images]
+        for im in imgs:
+            assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == 3, "uint8 HWC images expected"
+        B = len(imgs)
+        ptrs = (c_void_p * B)(*[im.data_ptr() for im in imgs])
+        ph, pw = c_int(0), c_int(0)
+        check(self.L.sylph_preprocess_u8(self._ctx, B, ptrs, _iarr([im.shape[0] for im in imgs]), _iarr([im.shape[1] for im in imgs]),
+                                         _iarr([s[0] for s in new_sizes]), _iarr([s[1] for s in new_sizes]), int(rgb_input),
+                                         ctypes.byref(ph), ctypes.byref(pw)), "preprocess_u8")
+        self._keep = imgs
+        self._batch = (B, ph.value, pw.value, [(int(s[0]), int(s[1])) for s in new_sizes])
+        return ph.value, pw.value
+
+    def export_input(self) -> torch.Tensor:
+        self._stream()
+        B, H, W, _ = self._batch
+        out = torch.empty(B, 3, H, W, device=self.device)
+        check(self.L.sylph_export_input(self._ctx, _ptr(out)), "export_input")
+        return out
+
     def backbone(self):
         self._stream()
         check(self.L.sylph_backbone_fpn(self._ctx), "backbone_fpn")

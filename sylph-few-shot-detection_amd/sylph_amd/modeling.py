@@ -221,11 +221,18 @@ class MetaOneStageDetector(nn.Module):
         assert w.dim() == 4, f"Weight has dimension: {w.dim()}"
         assert w.size(1) == 256
         eng = self.engine
-        images = [x["image"] for x in batched_inputs]
-        eng.preprocess(images)
+        if all("image_u8" in x for x in batched_inputs):
+            # fused input pipeline: the original uint8 HWC image + its ResizeShortestEdge target; resize,
+            # BGR conversion, normalisation and padding run in one HIP kernel (sylph_preprocess_u8)
+            sizes = [(int(x["resize_hw"][0]), int(x["resize_hw"][1])) for x in batched_inputs]
+            eng.preprocess_u8([x["image_u8"] for x in batched_inputs], sizes,
+                              rgb_input=str(batched_inputs[0].get("input_format", "BGR")) == "RGB")
+        else:
+            images = [x["image"] for x in batched_inputs]
+            eng.preprocess(images)
+            sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         eng.backbone()
         eng.head(w, b)
-        sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         out_sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
         dets = eng.decode(out_sizes)
         results = []

@@ -29,7 +29,9 @@ def resize_shortest_edge_shape(h: int, w: int, size: int, max_size: int) -> Tupl
 
 
 def resize_image(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
-    """uint8 HWC bilinear resize (detectron2 ResizeTransform uses PIL.Image.BILINEAR for uint8)."""
+    """Host resize of the fallback path (fused_preprocess=False): detectron2 ResizeTransform.apply_image, i.e.
+    PIL.Image.BILINEAR for uint8 images and, for any other dtype, torch F.interpolate(mode="bilinear",
+    align_corners=False) WITHOUT antialiasing (detectron2 does exactly that for non-uint8 input)."""
     if img.shape[0] == new_h and img.shape[1] == new_w:
         return img
     from PIL import Image
@@ -43,7 +45,7 @@ def resize_image(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
 class SylphPredictor:
     def __init__(self, config_file: str, weight_path: str, class_code_path: str,
                  runner_name: str = "sylph.runner.MetaFCOSRunner", test_dataset_names: Dict = None,
-                 dtype: Optional[str] = None):
+                 dtype: Optional[str] = None, fused_preprocess: bool = True):
         logger.info("SylphPredictor initializing...")
         runner = create_runner(runner_name)
         self.cfg = create_cfg(runner.get_default_cfg(), config_file, None).clone()
@@ -67,6 +69,8 @@ class SylphPredictor:
                 self.class_codes[split] = self._get_datasets_class_codes(self.metadatas[split], name)
         self.min_size = int(self.cfg.INPUT.MIN_SIZE_TEST)
         self.max_size = int(self.cfg.INPUT.MAX_SIZE_TEST)
+        self.fused_preprocess = fused_preprocess
+        self._pinned = {}  # (h, w) -> pinned uint8 staging buffer for the asynchronous H2D copy
         self.input_format = self.cfg.INPUT.FORMAT
         assert self.input_format in ["RGB", "BGR"], self.input_format
         logger.info("SylphPredictor done initialization")
@@ -95,10 +99,20 @@ class SylphPredictor:
         return codes
 
     def _preprocess(self, original_image: np.ndarray):
-        if self.input_format == "RGB":
-            original_image = original_image[:, :, ::-1]
         height, width = original_image.shape[:2]
         nh, nw = resize_shortest_edge_shape(height, width, self.min_size, self.max_size)
+        if self.fused_preprocess and original_image.dtype == np.uint8:
+            # sylph/predictor.py:259-269 on the GPU: the uint8 original goes to the device through a pinned staging
+            # buffer; resize (Pillow-exact), RGB->BGR, normalisation and padding are one kernel in front of the backbone
+            buf = self._pinned.get((height, width))
+            if buf is None:
+                if len(self._pinned) > 16:
+                    self._pinned.clear()
+                buf = self._pinned[(height, width)] = torch.empty(height, width, 3, dtype=torch.uint8, pin_memory=True)
+            buf.copy_(torch.from_numpy(np.ascontiguousarray(original_image)))
+            return {"image_u8": buf, "resize_hw": (nh, nw), "input_format": self.input_format, "height": height, "width": width}
+        if self.input_format == "RGB":
+            original_image = original_image[:, :, ::-1]
         image = resize_image(np.ascontiguousarray(original_image), nh, nw)
         image = torch.as_tensor(image.astype("float32").transpose(2, 0, 1))
         return {"image": image, "height": height, "width": width}

@@ -143,3 +143,55 @@ def test_predictor_roundtrip(sd, tmp_path, model):
     np.testing.assert_allclose(out.scores.cpu().numpy(), want["scores"].numpy(), atol=1e-3)
     # boxes are rescaled to the 90 x 130 original by detector_postprocess (factor <= 1 here): same bound
     _assert_boxes(out.pred_boxes.tensor.cpu().numpy(), want["pred_boxes"].numpy(), want["fpn_levels"].numpy())
+
+
+def test_fused_input_pipeline_is_bit_exact_with_pillow(golden_dir):
+    """sylph_preprocess_u8 (resize + BGR + normalise + pad in one kernel) vs outputs of the REAL Pillow (g9_resize.npz):
+    in fp32 mode the exported network input equals (PIL pixel - mean) exactly, for every up/down-sampling ratio; the pad
+    is zero; RGB input is swapped to BGR."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, "g9_resize.npz"))
+    eng = Engine(None, dtype="f32")
+    eng.load_state_dict(W.backbone_state_dict(0, depth=50))  # the input buffer belongs to the backbone plan
+    mean = np.array([103.530, 116.280, 123.675], np.float32).reshape(3, 1, 1)
+    cases = g["cases"]
+    imgs = [torch.from_numpy(g[f"in{i}"]) for i in range(len(cases))]
+    sizes = [(int(c[2]), int(c[3])) for c in cases]
+    ph, pw = eng.preprocess_u8(imgs, sizes)  # ONE ragged batch of all cases
+    assert ph % 32 == 0 and pw % 32 == 0 and ph >= max(s[0] for s in sizes) and pw >= max(s[1] for s in sizes)
+    x = eng.export_input().cpu().numpy()
+    for i, (nh, nw) in enumerate(sizes):
+        want = g[f"out{i}"].astype(np.float32).transpose(2, 0, 1) - mean
+        np.testing.assert_array_equal(x[i, :, :nh, :nw], want)
+        assert not x[i, :, nh:, :].any() and not x[i, :, :, nw:].any()
+    eng.preprocess_u8([imgs[0].flip(-1)], [sizes[0]], rgb_input=True)  # the same image given as RGB
+    np.testing.assert_array_equal(eng.export_input().cpu().numpy()[0, :, :sizes[0][0], :sizes[0][1]],
+                                  g["out0"].astype(np.float32).transpose(2, 0, 1) - mean)
+
+
+def test_predictor_fused_and_host_preprocess_agree(sd, tmp_path, model):
+    """SylphPredictor with the fused HIP input pipeline (default) and with the host PIL path give identical detections."""
+    from sylph_amd.data import SyntheticSupportSetLoader
+    from sylph_amd.evaluation import inference_normalization, inference_on_support_set_dataset
+    from sylph_amd.predictor import SylphPredictor
+    ckpt = str(tmp_path / "model_final.pth")
+    torch.save({"model": sd}, ckpt)
+    code_dir = str(tmp_path / "codes" / "synthetic_all" / "0")
+    sub = inference_normalization(model, inference_on_support_set_dataset(model, SyntheticSupportSetLoader(2, 1, 128, 160, seed=5)))
+    os.makedirs(code_dir)
+    for c in sub:
+        c["class_code"] = {k: v.cpu() for k, v in c["class_code"].items()}
+        c["class_code"]["cls_conv"] = c["class_code"]["cls_conv"] * 3.0
+        torch.save(c, os.path.join(code_dir, f"{c['class_name']}.pth"))
+    img = np.random.RandomState(1).randint(0, 256, size=(90, 130, 3), dtype=np.uint8)
+    outs = []
+    for fused in (True, False):
+        pred = SylphPredictor("sylph://COCO-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml", ckpt, str(tmp_path / "codes"),
+                              test_dataset_names={"all": "synthetic_all"}, dtype="f32", fused_preprocess=fused)
+        pred.min_size, pred.max_size = 96, 160
+        outs.append(pred._call_few_shot(img, pred.class_codes["all"])["instances"])
+    a, b = outs
+    assert len(a) == len(b) > 0 and a.image_size == b.image_size == (90, 130)
+    assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.scores, b.scores)
+    assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
