@@ -131,8 +131,10 @@ class MetaOneStageDetector(nn.Module):
         return self
 
     def load_checkpoint(self, path: str):
-        ckpt = torch.load(path, map_location="cpu", weights_only=False)
-        return self.load_state_dict(ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt)
+        """DetectionCheckpointer.load (sylph/predictor.py:87-88): model_final.pth, detectron2 model-zoo .pkl or the MSRA
+        R-50.pkl / R-101.pkl backbones the yamls name (sylph_amd.checkpoint maps them onto the reference keys)."""
+        from .checkpoint import load_checkpoint_file
+        return self.load_state_dict(load_checkpoint_file(path))
 
     def forward(self, batched_inputs, class_code=None, run_type=None):
         if self.training:

@@ -195,3 +195,35 @@ def test_predictor_fused_and_host_preprocess_agree(sd, tmp_path, model):
     assert len(a) == len(b) > 0 and a.image_size == b.image_size == (90, 130)
     assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.scores, b.scores)
     assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
+
+
+def test_msra_pkl_backbone_weights_run_like_reference_keys(tmp_path):
+    """An MSRA-style R-50.pkl (Caffe2 blob names, statistics absorbed) read by sylph_amd.checkpoint drives the HIP backbone
+    exactly like the same weights given under the reference keys."""
+    import pickle
+    from sylph_amd import synthetic as W
+    from sylph_amd.checkpoint import load_checkpoint_file
+    from sylph_amd.engine import Engine
+    from test_host_cpu import _to_caffe2
+    sd = W.backbone_state_dict(0, depth=50)
+    ref = dict(sd)
+    for k in list(ref):
+        if k.endswith("running_mean"):
+            ref[k] = torch.zeros_like(ref[k])
+        elif k.endswith("running_var"):
+            ref[k] = torch.ones_like(ref[k])
+    path = str(tmp_path / "R-50.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(_to_caffe2(sd), f)
+    loaded = load_checkpoint_file(path)
+    loaded.update({k: v for k, v in sd.items() if not k.startswith("backbone.bottom_up.")})  # FPN / P6 / P7 come from the detector checkpoint
+    imgs = W.synthetic_images(1, 64, 96, seed=2)
+    outs = []
+    for weights in (ref, loaded):
+        eng = Engine(None, dtype="f32")
+        eng.load_state_dict(weights)
+        eng.preprocess(imgs)
+        eng.backbone()
+        outs.append([p.cpu() for p in eng.export_pyramid()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -242,3 +242,54 @@ def test_detections_to_coco_rows_batches_one_copy():
     assert rows[0]["bbox"] == [1.0, 2.0, 10.0, 20.0] and rows[0]["category_id"] == 103
     assert rows[2]["bbox"] == [10.0, 10.0, 20.0, 40.0] and abs(rows[2]["score"] - 0.7) < 1e-6
     assert detections_to_coco_rows([inst([], [], [])], [1]) == []
+
+
+# ------------------------------------------------------------------------------------ checkpoint readers (8f-2)
+def _to_caffe2(sd):
+    """Inverse of the MSRA naming for the backbone part of a synthetic reference state dict (statistics absorbed)."""
+    inv = {"conv1": "branch2a", "conv2": "branch2b", "conv3": "branch2c", "shortcut": "branch1"}
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith("backbone.bottom_up.") or "running_" in k:
+            continue
+        k = k[len("backbone.bottom_up."):]
+        parts = k.split(".")
+        if parts[0] == "stem":
+            name = "conv1_w" if parts[-1] == "weight" and parts[-2] != "norm" else "res_conv1_bn_" + ("s" if parts[-1] == "weight" else "b")
+        else:
+            base = f"{parts[0]}_{parts[1]}_{inv[parts[2]]}"
+            name = base + ("_w" if parts[3] == "weight" else "_bn_" + ("s" if parts[-1] == "weight" else "b"))
+        out[name] = v.numpy()
+    out["fc1000_w"] = np.zeros((1000, 2048), np.float32)
+    out["fc1000_b"] = np.zeros((1000,), np.float32)
+    return out
+
+
+def test_checkpoint_readers_map_msra_and_model_zoo_names(tmp_path):
+    import pickle
+    from sylph_amd import synthetic as W
+    from sylph_amd.checkpoint import load_checkpoint_file
+    sd = W.backbone_state_dict(0, depth=50)
+    want = {k: v for k, v in sd.items() if k.startswith("backbone.bottom_up.") and "running_" not in k}
+    # (1) MSRA R-50.pkl: Caffe2 blob names, BN absorbed into (s, b)
+    p1 = str(tmp_path / "R-50.pkl")
+    with open(p1, "wb") as f:
+        pickle.dump(_to_caffe2(sd), f)
+    got = load_checkpoint_file(p1)
+    assert set(k for k in got if "running_" not in k) == set(want)
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+    assert float(got["backbone.bottom_up.res3.0.shortcut.norm.running_mean"].abs().sum()) == 0.0
+    assert torch.equal(got["backbone.bottom_up.stem.conv1.norm.running_var"], torch.ones(64))
+    # (2) detectron2 model-zoo pickle: {"model": {torch-style names without the backbone prefix: ndarray}}
+    p2 = str(tmp_path / "zoo.pkl")
+    with open(p2, "wb") as f:
+        pickle.dump({"model": {k[len("backbone.bottom_up."):]: v.numpy() for k, v in sd.items() if k.startswith("backbone.bottom_up.")},
+                     "__author__": "x", "matching_heuristics": True}, f)
+    got2 = load_checkpoint_file(p2)
+    assert all(torch.equal(got2[k], v) for k, v in sd.items() if k.startswith("backbone.bottom_up."))
+    # (3) training checkpoint model_final.pth: {"model": state_dict, "iteration": ...}
+    p3 = str(tmp_path / "model_final.pth")
+    torch.save({"model": sd, "iteration": 7}, p3)
+    got3 = load_checkpoint_file(p3)
+    assert set(got3) == set(sd) and all(torch.equal(got3[k], sd[k]) for k in sd)
