@@ -35,6 +35,12 @@ static int fail(const std::string& m) {
     int r_ = (x);                  \
     if (r_ != 0) return r_;        \
   } while (0)
+// build step of plan P: its allocations belong to P; a failed build releases the whole plan so that a retry starts clean
+#define BUILD(x, P)                                  \
+  do {                                               \
+    int r_ = (x);                                    \
+    if (r_ != 0) { drop_plan(c, (P)); return r_; }   \
+  } while (0)
 #define KCHK(x, what)                                                                              \
   do {                                                                                             \
     int r_ = (x);                                                                                  \
@@ -163,29 +169,31 @@ struct sylph_ctx {
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
 
-  int dalloc(void** p, size_t n) {
-    if (n == 0) n = 16;
-    hipError_t e = hipMalloc(p, n);
-    if (e != hipSuccess) return fail(std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
-    allocs.push_back(*p);
-    alloc_bytes[*p] = n;
-    bytes += (int64_t)n;
-    return 0;
-  }
-  std::map<void*, size_t> alloc_bytes;
-  void dfree(void* p) {  // release one dalloc'ed buffer (the stream may still use it: drain first)
+  // Plan cache policy: every allocation made while a plan is being built / grown is owned by that plan, and
+  // plans are evicted least-recently-used first once their count or their bytes exceed the budget, so a stream of
+  // distinct padded shapes (real COCO / LVIS episodes) cannot grow HBM without bound.
+  Plan* alloc_owner = nullptr;
+  uint64_t use_clock = 0;
+  size_t max_plans = 32;
+  int64_t plan_byte_budget = 0;  // 0 = set from the device size at context creation
+  int dalloc(void** p, size_t n);
+  void dfree_nosync(void* p) {
     if (!p) return;
-    (void)hipStreamSynchronize(stream);
     for (size_t i = 0; i < allocs.size(); ++i)
       if (allocs[i] == p) { allocs[i] = allocs.back(); allocs.pop_back(); break; }
     auto it = alloc_bytes.find(p);
     if (it != alloc_bytes.end()) { bytes -= (int64_t)it->second; alloc_bytes.erase(it); }
     (void)hipFree(p);
   }
+  std::map<void*, size_t> alloc_bytes;
+  void dfree(void* p);  // release one dalloc'ed buffer (the stream may still use it: drained first)
   size_t esz() const { return dt == DT_BF16 ? 2 : 4; }
 };
 
 struct Plan {
+  std::vector<void*> allocs;  // device buffers owned by this plan (freed on eviction)
+  int64_t bytes = 0;
+  uint64_t last_use = 0;
   int B = 0, H = 0, W = 0;
   int hl[8], wl[8], off[8], Ltot = 0;
   std::vector<int> img_h, img_w;
@@ -233,6 +241,52 @@ struct Plan {
   const float* cur_boxes = nullptr;
   float* cur_code_out = nullptr;
 };
+
+int sylph_ctx::dalloc(void** p, size_t n) {
+  if (n == 0) n = 16;
+  hipError_t e = hipMalloc(p, n);
+  if (e != hipSuccess) return fail(std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e));
+  allocs.push_back(*p);
+  alloc_bytes[*p] = n;
+  bytes += (int64_t)n;
+  if (alloc_owner) { alloc_owner->allocs.push_back(*p); alloc_owner->bytes += (int64_t)n; }
+  return 0;
+}
+
+void sylph_ctx::dfree(void* p) {
+  if (!p) return;
+  (void)hipStreamSynchronize(stream);
+  for (auto& kv : plans) {
+    auto& v = kv.second->allocs;
+    for (size_t i = 0; i < v.size(); ++i)
+      if (v[i] == p) {
+        auto it = alloc_bytes.find(p);
+        if (it != alloc_bytes.end()) kv.second->bytes -= (int64_t)it->second;
+        v[i] = v.back(); v.pop_back();
+        break;
+      }
+  }
+  dfree_nosync(p);
+}
+
+// allocations made inside the scope belong to plan P (nullptr: to the context, e.g. re-packed weights)
+struct OwnerScope {
+  sylph_ctx* c; Plan* prev;
+  OwnerScope(sylph_ctx* c_, Plan* P) : c(c_), prev(c_->alloc_owner) { c->alloc_owner = P; }
+  ~OwnerScope() { c->alloc_owner = prev; }
+};
+
+static void free_plan(sylph_ctx* c, Plan* P) {
+  (void)hipStreamSynchronize(c->stream);
+  for (void* p : P->allocs) c->dfree_nosync(p);
+  P->allocs.clear();
+  if (P->img_desc_host) (void)hipHostFree(P->img_desc_host);
+  if (P->img_out_host) (void)hipHostFree(P->img_out_host);
+  if (P->rz_host) (void)hipHostFree(P->rz_host);
+  if (P->img_out_ev) (void)hipEventDestroy(P->img_out_ev);
+  if (P->img_desc_ev) (void)hipEventDestroy(P->img_desc_ev);
+  if (c->cur == P) c->cur = nullptr;
+}
 
 // ------------------------------------------------------------------------------------------------
 static int upload(sylph_ctx* c, void** dev, const void* host, size_t n) {
@@ -553,6 +607,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
     auto it = c->hp_weights.find(L.w);
     if (it == c->hp_weights.end()) {
       void* wp = nullptr;
+      OwnerScope ctx_owned(c, nullptr);  // a layer's re-packed weights outlive the plan that first needed them
       RET(c->dalloc(&wp, (size_t)L.Cout * 9 * L.Cin * 2));
       KCHK(launch_hpipe_pack_weights(L.w, wp, L.Cout, L.Cin, c->stream), "hpipe_pack_weights");
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -628,11 +683,31 @@ static std::vector<SegDesc> image_segs(int B, int Hin, int Win, int Hout, int Wo
   return v;
 }
 
+static void evict_plans(sylph_ctx* c, const Plan* keep) {
+  auto total = [&]() { int64_t t = 0; for (auto& kv : c->plans) t += kv.second->bytes; return t; };
+  while (c->plans.size() > 1 && (c->plans.size() >= c->max_plans || (c->plan_byte_budget > 0 && total() > c->plan_byte_budget))) {
+    auto victim = c->plans.end();
+    for (auto it = c->plans.begin(); it != c->plans.end(); ++it)
+      if (it->second.get() != keep && it->second.get() != c->cur &&
+          (victim == c->plans.end() || it->second->last_use < victim->second->last_use)) victim = it;
+    if (victim == c->plans.end()) break;
+    free_plan(c, victim->second.get());
+    c->plans.erase(victim);
+  }
+}
+
+static void drop_plan(sylph_ctx* c, Plan* P) {  // a plan whose build failed half way: release it so that a retry starts clean
+  for (auto it = c->plans.begin(); it != c->plans.end(); ++it)
+    if (it->second.get() == P) { free_plan(c, P); c->plans.erase(it); return; }
+}
+
 static Plan* get_plan(sylph_ctx* c, int B, int H, int W) {
   auto key = std::make_tuple(B, H, W);
   auto it = c->plans.find(key);
-  if (it != c->plans.end()) return it->second.get();
+  if (it != c->plans.end()) { it->second->last_use = ++c->use_clock; return it->second.get(); }
+  evict_plans(c, nullptr);
   std::unique_ptr<Plan> p(new Plan());
+  p->last_use = ++c->use_clock;
   p->B = B; p->H = H; p->W = W;
   level_dims(c->cfg, H, W, p->hl, p->wl, p->off, &p->Ltot);
   p->img_h.assign(B, H);
@@ -1154,6 +1229,12 @@ int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out) {
   c->dt = dtype == SYLPH_BF16 ? DT_BF16 : DT_F32;
   sylph_config_default(&c->cfg);
   if (const char* nb = getenv("SYLPH_CONV_NBUF")) conv_set_nbuf(atoi(nb));  // tuning knob: LDS stages of the conv kernel
+  if (const char* mp = getenv("SYLPH_MAX_PLANS")) c->max_plans = atoi(mp) > 1 ? (size_t)atoi(mp) : 2;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->plan_byte_budget = (int64_t)(total_b / 10 * 6);  // 60 % of HBM for workspaces
+    if (const char* pb = getenv("SYLPH_PLAN_BYTES_MB")) c->plan_byte_budget = (int64_t)atol(pb) << 20;
+  }
   if (c->dalloc(&c->zeros, 256) != 0 || hipMemset(c->zeros, 0, 256) != hipSuccess) {
     delete c;
     return fail("cannot allocate the zero page");
@@ -1166,13 +1247,8 @@ void sylph_ctx_destroy(sylph_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (auto& kv : c->plans) {
-    if (kv.second->img_desc_host) (void)hipHostFree(kv.second->img_desc_host);
-    if (kv.second->img_out_host) (void)hipHostFree(kv.second->img_out_host);
-    if (kv.second->img_out_ev) (void)hipEventDestroy(kv.second->img_out_ev);
-    if (kv.second->img_desc_ev) (void)hipEventDestroy(kv.second->img_desc_ev);
-    if (kv.second->rz_host) (void)hipHostFree(kv.second->rz_host);
-  }
+  for (auto& kv : c->plans) free_plan(c, kv.second.get());
+  c->plans.clear();
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;
 }
@@ -1469,7 +1545,8 @@ int sylph_preprocess(sylph_ctx* c, int B, const float* const* images, const int*
   const int d = c->cfg.size_divisibility;
   if (d > 1) { mh = (mh + d - 1) / d * d; mw = (mw + d - 1) / d * d; }
   Plan* P = get_plan(c, B, mh, mw);
-  RET(build_backbone(c, P));
+  OwnerScope own(c, P);
+  BUILD(build_backbone(c, P), P);
   // the previous batch's H2D copy of the pinned descriptor table must have been consumed: wait for THAT copy only
   // (an event), not for the stream: the host stays free to enqueue the next step behind the running one
   if (P->img_desc_ev) HIPCHK(hipEventSynchronize(P->img_desc_ev));
@@ -1501,7 +1578,8 @@ int sylph_preprocess_u8(sylph_ctx* c, int B, const unsigned char* const* images,
   const int d = c->cfg.size_divisibility;
   if (d > 1) { mh = (mh + d - 1) / d * d; mw = (mw + d - 1) / d * d; }
   Plan* P = get_plan(c, B, mh, mw);
-  RET(build_backbone(c, P));
+  OwnerScope own(c, P);
+  BUILD(build_backbone(c, P), P);
   // resampling tables of every image (cached per (in, out) size pair), laid out back to back
   std::vector<std::shared_ptr<PilCoeffs>> hc((size_t)B), vc((size_t)B);
   size_t nint = 0;
@@ -1569,7 +1647,8 @@ int sylph_import_pyramid(sylph_ctx* c, int B, int H, int W, const int* hs, const
   if (!c->finalized) return fail("weights not finalized");
   HIPCHK(hipSetDevice(c->device));
   Plan* P = get_plan(c, B, H, W);
-  RET(ensure_pyramid(c, P));
+  OwnerScope own(c, P);
+  BUILD(ensure_pyramid(c, P), P);
   for (int b = 0; b < B; ++b) { P->img_h[b] = hs ? hs[b] : H; P->img_w[b] = ws ? ws[b] : W; }
   for (int l = 0; l < c->cfg.nlevels; ++l) {
     const int hw = P->hl[l] * P->wl[l];
@@ -1621,7 +1700,8 @@ int sylph_import_head(sylph_ctx* c, int N, int level, const float* logits, const
   if (!P) return fail("no current batch");
   if (N <= 0) return fail("class_code is empty");
   if (level < 0 || level >= c->cfg.nlevels) return fail("bad level");
-  RET(build_head(c, P));
+  OwnerScope own(c, P);
+  BUILD(build_head(c, P), P);
   if (!P->logits || N != P->ncls) RET(ensure_logits(c, P, N));
   const int hw = P->hl[level] * P->wl[level];
   for (int b = 0; b < P->B; ++b) {
@@ -1662,7 +1742,8 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   if (!P) return fail("no current batch");
   if (N <= 0) return fail("class_code is empty");
   if (!cls_conv) return fail("cls_conv is NULL");
-  RET(build_head(c, P));
+  OwnerScope own(c, P);
+  BUILD(build_head(c, P), P);
   const size_t rows = (size_t)P->B * P->Ltot;
   const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
   const int Npad = (N + bn - 1) / bn * bn;
@@ -1707,7 +1788,8 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   Plan* P = c->cur;
   if (!P || !P->head_built || !P->logits) return fail("sylph_fcos_head must be called first");
   if (max_out <= 0) return fail("max_out must be positive");
-  RET(build_decode(c, P));
+  OwnerScope own(c, P);
+  BUILD(build_decode(c, P), P);
   if (want_cand_cap(c, P) > P->cand_cap) {  // more classes than when the plan was built: grow the candidate buffers
     const int nseg = P->B * c->cfg.nlevels;
     P->cand_cap = want_cand_cap(c, P);
@@ -1749,8 +1831,9 @@ int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
   Plan* P = c->cur;
   if (!P) return fail("no current batch");
   if (!boxes || !code_out) return fail("NULL argument");
-  if (c->cfg.cg_type == 1) RET(build_support_roienc(c, P));
-  else RET(build_support(c, P));
+  OwnerScope own(c, P);
+  if (c->cfg.cg_type == 1) BUILD(build_support_roienc(c, P), P);
+  else BUILD(build_support(c, P), P);
   P->cur_boxes = boxes;
   P->cur_code_out = code_out;
   return run_ops(c, P->support_ops, "codegen");

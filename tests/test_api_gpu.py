@@ -227,3 +227,39 @@ def test_msra_pkl_backbone_weights_run_like_reference_keys(tmp_path):
         outs.append([p.cpu() for p in eng.export_pyramid()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_plan_cache_is_bounded_lru(sd, monkeypatch):
+    """a stream of distinct padded shapes must not grow HBM without bound.  With SYLPH_MAX_PLANS=3 six shapes
+    keep at most three workspaces alive, an evicted shape is rebuilt transparently and gives identical results."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.engine import Engine
+    monkeypatch.setenv("SYLPH_MAX_PLANS", "3")
+    eng = Engine(None, dtype="bf16")
+    eng.load_state_dict(sd)
+    codes = W.synthetic_codes(5, seed=4, scale=3.0)
+
+    def run(h, w):
+        eng.preprocess(W.synthetic_images(1, h, w, seed=h + w))
+        eng.backbone()
+        eng.head(codes["cls_conv"], codes["cls_bias"])
+        d = eng.decode()[0]
+        return d["scores"].clone(), d["pred_boxes"].clone(), eng.device_bytes()
+
+    first = run(96, 128)
+    peak = 0
+    for h, w in ((128, 160), (160, 192), (192, 224), (224, 256), (256, 288)):
+        peak = max(peak, run(h, w)[2])
+    again = run(96, 128)  # evicted by now: rebuilt from scratch
+    assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+    big3 = 3 * run(256, 288)[2]  # loose upper bound: three times the footprint with the largest shape resident
+    assert peak < big3
+    monkeypatch.setenv("SYLPH_MAX_PLANS", "64")
+    eng2 = Engine(None, dtype="bf16")
+    eng2.load_state_dict(sd)
+    eng_bytes = []
+    for h, w in ((96, 128), (128, 160), (160, 192), (192, 224), (224, 256), (256, 288)):
+        eng2.preprocess(W.synthetic_images(1, h, w, seed=h + w)); eng2.backbone()
+        eng2.head(codes["cls_conv"], codes["cls_bias"]); eng2.decode()
+        eng_bytes.append(eng2.device_bytes())
+    assert eng_bytes[-1] > peak, (eng_bytes, peak)  # without eviction the six workspaces add up beyond the bounded engine's peak
