@@ -62,6 +62,8 @@ typedef struct sylph_config {
   int enc_layers;          /* TRANSFORMER_ENCODER.LAYERS */
   int head_num_fc;         /* HEAD.NUM_FC */
   int head_fc_dim;         /* HEAD.FC_DIM (OUTPUT_DIM 256) */
+  int cg_meta_bias;        /* CODE_GENERATOR.META_BIAS: the bias prior is the learned parameter
+                              code_generator.code_generator_head.bias_value of the checkpoint (code_generator.py:422-425,856) */
 } sylph_config;
 
 /* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */

@@ -146,6 +146,7 @@ struct sylph_ctx {
   ConvLayer cg_cls, cg_bias;
   GNLayer cg_post;
   float cg_conv_scale = 1.f, cg_bias_scale = 1.f;
+  float cg_bias_prior = 0.f;  // bias_value: -log((1 - PRIOR_PROB) / PRIOR_PROB), or the learned parameter with META_BIAS
   // ROIEncoder variant
   struct Lin { float* W = nullptr; float* b = nullptr; int K = 0, O = 0; };
   struct EncLayer { Lin attn, l1, l2; GNLayer n1, n2; };
@@ -1162,7 +1163,7 @@ static int build_support_roienc(sylph_ctx* c, Plan* P) {
     float* cls = P->re_cls;
     float* x = tok;
     ops.push_back([=](hipStream_t s) { return launch_mean_tokens(x, S, cls, s); });
-    const float prior = -logf((1.f - c->cfg.prior_prob) / c->cfg.prior_prob);
+    const float prior = -logf((1.f - 0.01f) / 0.01f);  // ROIEncoder hard-codes prior_prob = 0.01 (roi_encoder.py:139-140), whatever MODEL.FCOS.PRIOR_PROB says
     for (int head = 0; head < 2; ++head) {
       const std::vector<sylph_ctx::Lin>& fcs = head == 0 ? R.wh : R.bh;
       const float* in = cls;
@@ -1213,6 +1214,7 @@ void sylph_config_default(sylph_config* cfg) {
   cfg->cg_conv_l2_norm = 1; cfg->cg_use_weight_scale = 1; cfg->prior_prob = 0.01f; cfg->cand_cap = 0;
   cfg->cg_type = 0; cfg->tok_num_conv = 2; cfg->tok_num_fc = 2; cfg->enc_layers = 2; cfg->head_num_fc = 2;
   cfg->head_fc_dim = 512;
+  cfg->cg_meta_bias = 0;
 }
 
 const char* sylph_last_error(void) { return g_err.c_str(); }
@@ -1440,6 +1442,12 @@ int sylph_finalize_weights(sylph_ctx* c) {
       const HostTensor* s = find_w(c, cp + ".bias_scale.scale");
       if (!s) return fail("missing " + cp + ".bias_scale.scale");
       c->cg_bias_scale = s->data[0];
+    }
+    c->cg_bias_prior = -logf((1.f - c->cfg.prior_prob) / c->cfg.prior_prob);
+    if (c->cfg.cg_meta_bias) {
+      const HostTensor* bv = find_w(c, cp + ".bias_value");
+      if (!bv || bv->data.empty()) return fail("META_BIAS is set but " + cp + ".bias_value is missing from the checkpoint");
+      c->cg_bias_prior = bv->data[0];
     }
     c->has_codegen = true;
   }
@@ -1842,7 +1850,7 @@ int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
 int sylph_normalize_codes(sylph_ctx* c, float* codes, int n, const float* weight_norm) {
   if (!c->has_codegen) return fail("code generator weights were not loaded");
   if (n <= 0) return 0;
-  const float prior = -logf((1.f - c->cfg.prior_prob) / c->cfg.prior_prob);
+  const float prior = c->cg_bias_prior;
   KCHK(launch_normalize_codes(codes, n, 256, c->cg_post.gamma, c->cg_post.beta, c->cfg.cg_post_norm,
                               c->cfg.cg_conv_l2_norm, c->cg_conv_scale, c->cg_bias_scale, prior, weight_norm, c->stream),
        "normalize_codes");

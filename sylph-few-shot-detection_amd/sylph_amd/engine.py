@@ -64,6 +64,20 @@ def config_from_cfg(cfg) -> SylphConfig:
         raise NotImplementedError(f"MODEL.FCOS.BOX_QUALITY {bq}")
     sc.prior_prob = float(f.PRIOR_PROB)
     cg = m.META_LEARN.CODE_GENERATOR
+    # knobs that change the reference arithmetic and are not implemented must fail loudly, not be ignored
+    if int(m.RESNETS.get("RES5_DILATION", 1)) != 1:
+        raise NotImplementedError("MODEL.RESNETS.RES5_DILATION != 1 is not supported")
+    if bool(m.PROPOSAL_GENERATOR.get("OWD", False)):
+        raise NotImplementedError("MODEL.PROPOSAL_GENERATOR.OWD is not supported")
+    if bool(cg.ROI_BOX.get("FPN_MULTILEVEL_FEATURE", False)):
+        raise NotImplementedError("CODE_GENERATOR.ROI_BOX.FPN_MULTILEVEL_FEATURE is not supported")
+    # (USE_PER_CLS_SCALE is set by the LVIS yamls but never read by the reference; INIT_NORM_LAYER only affects initialisation)
+    for knob in ("ALL_MASK", "USE_DEFORMABLE", "META_WEIGHT"):
+        if bool(cg.get(knob, False)):
+            raise NotImplementedError(f"CODE_GENERATOR.{knob} is not supported")
+    if str(cg.ROI_BOX.get("POOLER_TYPE", "ROIAlignV2")) != "ROIAlignV2":
+        raise NotImplementedError("CODE_GENERATOR.ROI_BOX.POOLER_TYPE must be ROIAlignV2")
+    sc.cg_meta_bias = int(bool(cg.get("META_BIAS", False)))
     sc.cond_use_bias = int(bool(cg.USE_BIAS))
     if str(cg.NAME) == "ROIEncoder":
         # sylph/modeling/code_generator/roi_encoder.py:206-281 (dims of the LVIS ROI-Encoder yaml)
@@ -91,6 +105,8 @@ def config_from_cfg(cfg) -> SylphConfig:
         raise NotImplementedError(f"CODE_GENERATOR.CLS_LAYER {cl} (only ['', '', 1])")
     bl = list(cg.BIAS_LAYER)
     sc.cg_has_bias = int(len(bl) != 0)
+    if len(bl) and (len(bl) != 3 or bl[0] not in ("", "none") or bl[1] != "" or int(bl[2]) != 1):
+        raise NotImplementedError(f"CODE_GENERATOR.BIAS_LAYER {bl} (only [] or ['', '', 1]: no norm, no ReLU, one conv)")
     if len(cg.WEIGHT_LAYER) or len(cg.SCALE_LAYER):
         raise NotImplementedError("CODE_GENERATOR.WEIGHT_LAYER / SCALE_LAYER are not supported")
     if bool(cg.COMPRESS_CODE_W_MAX) or bool(cg.CLS_REWEIGHT) or bool(cg.BOX_ON):
