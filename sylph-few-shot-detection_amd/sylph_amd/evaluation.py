@@ -185,27 +185,56 @@ def inference_on_dataset_with_class_codes(model, data_loader, evaluator, class_c
     return results if results is not None else {}
 
 
-def detections_to_coco_rows(outputs: List[Dict[str, Any]], image_ids: List[int],
-                            contiguous_to_dataset_id: Dict[int, int] = None) -> List[Dict[str, Any]]:
-    """Result sink: COCO-json rows for a whole batch with ONE device->host copy.
+DET_ROW = 8  # image id | x0 | y0 | x1 | y1 | score | contiguous class id | valid
 
-    The reference converts per image (`instances_to_coco_json` in the d2 evaluators called from
-    meta_learn_evaluation.py:428,465: one `.to(cpu)` per field per image).  Here the boxes / scores / classes of every
-    image of the batch are concatenated on the device, copied once, and split on the host.  Boxes go from XYXY to the
-    COCO XYWH convention."""
+
+def detections_to_tensor(outputs: List[Dict[str, Any]], image_ids: List[int]) -> torch.Tensor:
+    """Result sink, device side: every detection of a batch as one dense (n, 8) fp32 tensor on the device
+    (image id, XYXY box, score, class, valid) -- no per-image / per-field .cpu() as in the d2 evaluators the reference
+    calls from meta_learn_evaluation.py:428,465.  Image ids must be < 2^24 (exact in fp32)."""
     assert len(outputs) == len(image_ids)
     insts = [o["instances"] for o in outputs]
-    counts = [len(i) for i in insts]
-    if sum(counts) == 0:
-        return []
-    packed = torch.cat([torch.cat([i.pred_boxes.tensor.float(), i.scores.float().unsqueeze(1),
-                                   i.pred_classes.float().unsqueeze(1)], dim=1) for i in insts if len(i) > 0]).cpu()
-    rows, k = [], 0
-    for img_id, n in zip(image_ids, counts):
-        blk = packed[k:k + n].tolist()
-        k += n
-        for x0, y0, x1, y1, s, c in blk:
-            cid = int(c)
-            rows.append({"image_id": img_id, "category_id": contiguous_to_dataset_id[cid] if contiguous_to_dataset_id else cid,
-                         "bbox": [x0, y0, x1 - x0, y1 - y0], "score": s})
-    return rows
+    dev = insts[0].pred_boxes.tensor.device if insts else torch.device("cpu")
+    parts = []
+    for img_id, i in zip(image_ids, insts):
+        n = len(i)
+        if n == 0:
+            continue
+        assert 0 <= int(img_id) < (1 << 24)
+        parts.append(torch.cat([torch.full((n, 1), float(img_id), device=dev), i.pred_boxes.tensor.float(),
+                                i.scores.float().unsqueeze(1), i.pred_classes.float().unsqueeze(1),
+                                torch.ones(n, 1, device=dev)], dim=1))
+    return torch.cat(parts) if parts else torch.zeros(0, DET_ROW, device=dev)
+
+
+def gather_detection_rows(local: torch.Tensor, capacity: int) -> torch.Tensor:
+    """Prediction gather across ranks (the reference pickles lists through comm.gather inside the evaluators): ONE
+    all_gather_into_tensor of equal-size (capacity, 8) blocks, rank order preserved; rows with valid = 0 are padding.
+    capacity >= the largest per-rank detection count (e.g. images per rank x POST_NMS_TOPK_TEST + ties)."""
+    import torch.distributed as dist
+    assert local.shape[0] <= capacity, f"{local.shape[0]} detections do not fit the gather block of {capacity}"
+    block = torch.zeros(capacity, DET_ROW, dtype=torch.float32, device=local.device)
+    block[: local.shape[0]] = local
+    if not (dist.is_available() and dist.is_initialized()):
+        return block
+    out = torch.empty(dist.get_world_size() * capacity, DET_ROW, dtype=torch.float32, device=local.device)
+    dist.all_gather_into_tensor(out, block)
+    return out
+
+
+def detection_rows_to_coco(rows: torch.Tensor, contiguous_to_dataset_id: Dict[int, int] = None) -> List[Dict[str, Any]]:
+    """(n, 8) rows (ONE device->host copy here) -> COCO-json result dicts, boxes XYXY -> XYWH."""
+    rows = rows.cpu()
+    rows = rows[rows[:, 7] > 0].tolist()
+    out = []
+    for img_id, x0, y0, x1, y1, s, c, _ in rows:
+        cid = int(c)
+        out.append({"image_id": int(img_id), "category_id": contiguous_to_dataset_id[cid] if contiguous_to_dataset_id else cid,
+                    "bbox": [x0, y0, x1 - x0, y1 - y0], "score": s})
+    return out
+
+
+def detections_to_coco_rows(outputs: List[Dict[str, Any]], image_ids: List[int],
+                            contiguous_to_dataset_id: Dict[int, int] = None) -> List[Dict[str, Any]]:
+    """COCO-json rows for a whole batch with ONE device->host copy (detections_to_tensor + detection_rows_to_coco)."""
+    return detection_rows_to_coco(detections_to_tensor(outputs, image_ids), contiguous_to_dataset_id)

@@ -263,3 +263,32 @@ def test_plan_cache_is_bounded_lru(sd, monkeypatch):
         eng2.head(codes["cls_conv"], codes["cls_bias"]); eng2.decode()
         eng_bytes.append(eng2.device_bytes())
     assert eng_bytes[-1] > peak, (eng_bytes, peak)  # without eviction the six workspaces add up beyond the bounded engine's peak
+
+
+def test_result_sink_on_model_outputs(model, sd):
+    """Result sink (8f-4) on real device outputs: the batched conversion (one device->host copy) equals the per-image,
+    per-field conversion the d2 evaluators do (meta_learn_evaluation.py:428,465), and a single-rank prediction gather
+    keeps the rows."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.data import SyntheticQueryLoader
+    from sylph_amd.evaluation import detection_rows_to_coco, detections_to_coco_rows, detections_to_tensor, gather_detection_rows
+    codes = W.synthetic_codes(3, seed=4, scale=3.0)
+    batch = next(iter(SyntheticQueryLoader(3, 120, 152, batch_size=3, seed=8)))
+    outs = model(batch, class_code={k: v.cuda() for k, v in codes.items()}, run_type="meta_learn_test_instance")
+    ids = [b["image_id"] + 100 for b in batch]
+    rows = detections_to_coco_rows(outs, ids, {0: 7, 1: 8, 2: 9})
+    want = []
+    for img_id, o in zip(ids, outs):  # the reference way: per image, per field
+        i = o["instances"]
+        bx, sc, cl = i.pred_boxes.tensor.cpu().tolist(), i.scores.cpu().tolist(), i.pred_classes.cpu().tolist()
+        for b, s, c in zip(bx, sc, cl):
+            want.append({"image_id": img_id, "category_id": {0: 7, 1: 8, 2: 9}[c], "bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]], "score": s})
+    assert len(rows) == len(want) > 0
+    for r, w in zip(rows, want):
+        assert r["image_id"] == w["image_id"] and r["category_id"] == w["category_id"]
+        np.testing.assert_allclose(r["bbox"], w["bbox"], rtol=1e-6, atol=1e-4)
+        assert abs(r["score"] - w["score"]) < 1e-6
+    t = detections_to_tensor(outs, ids)
+    assert t.is_cuda and t.shape == (len(want), 8)
+    g = gather_detection_rows(t, capacity=len(want) + 5)
+    assert len(detection_rows_to_coco(g)) == len(want)

@@ -293,3 +293,36 @@ def test_checkpoint_readers_map_msra_and_model_zoo_names(tmp_path):
     torch.save({"model": sd, "iteration": 7}, p3)
     got3 = load_checkpoint_file(p3)
     assert set(got3) == set(sd) and all(torch.equal(got3[k], sd[k]) for k in sd)
+
+
+def _det_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sylph_amd.evaluation import detection_rows_to_coco, detections_to_tensor, gather_detection_rows
+        from sylph_amd.structures import Boxes, Instances
+
+        def inst(n, base):
+            r = Instances((100, 200))
+            r.pred_boxes = Boxes(torch.arange(n * 4, dtype=torch.float32).reshape(n, 4) + base)
+            r.scores = torch.linspace(0.9, 0.1, n) if n else torch.zeros(0)
+            r.pred_classes = torch.arange(n) % 3
+            return {"instances": r}
+        outs, ids = ([inst(2, 0), inst(0, 0)], [10, 11]) if rank == 0 else ([inst(3, 100)], [12])
+        rows = gather_detection_rows(detections_to_tensor(outs, ids), capacity=4)
+        if rank == 0:
+            torch.save(detection_rows_to_coco(rows, {0: 5, 1: 6, 2: 7}), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prediction_gather_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dets.pt")
+    mp.spawn(_det_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=False)
+    assert [r["image_id"] for r in res] == [10, 10, 12, 12, 12]
+    assert [r["category_id"] for r in res] == [5, 6, 5, 6, 7]
+    assert res[2]["bbox"] == [100.0, 101.0, 2.0, 2.0] and abs(res[0]["score"] - 0.9) < 1e-6
