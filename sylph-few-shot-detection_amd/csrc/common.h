@@ -54,6 +54,8 @@ struct ConvArgs {
   int ss_padded;              // scale/shift arrays are padded to a multiple of the N tile (vector prefetch allowed)
   int stem;                   // ResNet-stem A loader (see conv_igemm.hip)
   int tap_dy;                 // input rows advanced per kernel-row tap (1; stem: rows per K-slice)
+  const float2* gn_coef;      // conv_hpipe.hip: fused GroupNorm(+ReLU) of the INPUT: per (segment, input channel) (a, b),
+  int gn_relu;                //   x <- relu?(a * x + b) applied to the landed halo in LDS; row stride of gn_coef = in_ld
 };
 
 template <typename T> struct Cvt;

@@ -65,7 +65,9 @@ constexpr int NSTAGE = 4;
 constexpr int HPROWS = 256;                    // halo rows reserved per patch
 constexpr int HBUF = 2 * HPROWS * 64;          // one halo buffer (both patches)
 constexpr int HALO_OFF = NSTAGE * BSTAGE;
-constexpr int LDS_BYTES = HALO_OFF + 2 * HBUF;  // 131 072
+constexpr int COEF_OFF = HALO_OFF + 2 * HBUF;   // fused input GroupNorm: (a, b) per patch and input channel, [2][Cin] float2
+constexpr int COEF_MAX_CIN = 512;
+constexpr int LDS_BYTES = COEF_OFF + 2 * COEF_MAX_CIN * 8;  // 139 264
 constexpr int SCP = 256 + 4;                   // fp32 pitch of the epilogue tile
 static_assert(64 * SCP * 4 <= LDS_BYTES, "epilogue tile must fit");
 
@@ -90,6 +92,7 @@ constexpr int nload(int t) { return ((t % 9 + 9) % 9) < NPIECE ? 3 : 2; }
 #define HP_WAITL() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 }  // namespace
 
+template <bool GNIN>
 __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   // Each lane keeps a running 64-bit source pointer per halo piece (advanced by 64 B per half-slice; lanes outside the
   // image / past the halo stay on the zero page), so issuing a piece costs no VALU work.
   const char* hptr[NPIECE];
-  unsigned hmask = 0;
+  unsigned hmask = 0, hcs = 0;  // per piece: inside the image?  / logical 16-byte chunk (8 channels) this lane fetches
 #pragma unroll
   for (int g = 0; g < NPIECE; ++g) {
     const bool p1 = g >= NPIECE / 2;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
     const int iy = (ty >> 16) - 1 + hy, ix = (ty & 0xffff) - 1 + hx;
     const bool ok = h < HR && hx < PW + 2 && (unsigned)iy < (unsigned)sd.in_H && (unsigned)ix < (unsigned)sd.in_W;
     const int cs = s4 ^ (((hy * PW + hx) >> 2) & 3);
+    hcs |= (unsigned)cs << (2 * g);
     hptr[g] = ok ? reinterpret_cast<const char*>(in + ((size_t)(sd.in_row0 + iy * sd.in_W + ix) * a.in_ld + cs * 8 + goff + c0 * 32))
                  : reinterpret_cast<const char*>(zero + s4 * 8);
     hmask |= (ok ? 1u : 0u) << g;
@@ -170,6 +174,51 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
     }
   };
   auto rot = [&](int cc) { const int c = c0 + cc; return c >= ncc ? c - ncc : c; };
+
+  // Fused GroupNorm(+ReLU) of the input (a.gn_coef): every lane rewrites, in LDS, exactly the 16 bytes (8 channels of one
+  // halo position) it fetched itself -- so the only ordering it needs is its own vmcnt wait for that load -- as
+  // bf16(relu(a * x + b)).  Lanes on the zero page (conv padding, halo pad entries) are skipped: the padding of the
+  // NORMALISED tensor is zero.  Readers see the result after the next lgkmcnt(0) + barrier, phases before its first use.
+  constexpr bool gn_in = GNIN;  // the plain instantiation carries none of this
+  const bool gn_relu = a.gn_relu != 0;
+  // The LDS accesses are inline asm: for a compiler-visible ds_read hipcc inserts s_waitcnt vmcnt(0) (it must assume the
+  // LDS-DMA still in flight aliases the read), which would drain the whole load pipeline in 4 of 9 phases.  The data read
+  // here was fetched by THIS lane and retired by this wave's counted vmcnt two phases ago; the lgkmcnt wait is tied to the
+  // loaded registers ("+v") so that no consumer can be scheduled above it.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  u32x4 gx;
+  f32x4v gc0, gc1, gc2, gc3;  // (a, b) pairs of channels (0,1) (2,3) (4,5) (6,7)
+  auto gn_addr = [&](int g, int cc_of_piece) { return lds0 + HALO_OFF + (cc_of_piece & 1) * HBUF + g * 8192 + tid * 16; };
+  auto gn_read = [&](int g, int cc_of_piece) {  // issue the five LDS reads of piece g (no wait)
+    const unsigned d = gn_addr(g, cc_of_piece);
+    const int ch = rot(cc_of_piece) * 32 + (int)((hcs >> (2 * g)) & 3u) * 8;
+    const unsigned cf = lds0 + COEF_OFF + ((g >= NPIECE / 2 ? Cin : 0) + ch) * 8;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(gx) : "v"(d));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(gc0) : "v"(cf));
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(gc1) : "v"(cf));
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(gc2) : "v"(cf));
+    asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(gc3) : "v"(cf));
+  };
+  auto gn_finish = [&](int g, int cc_of_piece) {  // wait for them, transform, write back (branch-free: no cut in the MFMA stream)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gx), "+v"(gc0), "+v"(gc1), "+v"(gc2), "+v"(gc3));
+    const bool live = (hmask >> g) & 1u;
+    const f32x4v cs[4] = {gc0, gc1, gc2, gc3};
+    u32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo = fmaf(__uint_as_float(gx[e] << 16), cs[e][0], cs[e][1]);
+      float hi = fmaf(__uint_as_float(gx[e] & 0xffff0000u), cs[e][2], cs[e][3]);
+      if (gn_relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      bf16x2 pk;
+      pk[0] = (bf16_t)lo; pk[1] = (bf16_t)hi;
+      y[e] = live ? *reinterpret_cast<unsigned*>(&pk) : gx[e];  // zero-page lanes keep their zeros
+    }
+    asm volatile("ds_write_b128 %0, %1" ::"v"(gn_addr(g, cc_of_piece)), "v"(y) : "memory");
+  };
+  auto gn_piece = [&](int g, int cc_of_piece) { gn_read(g, cc_of_piece); gn_finish(g, cc_of_piece); };
 
   // ---- fragment addressing -----------------------------------------------------------------------------------------
   const SegDesc& sdm = wm ? sd1 : sd0;  // this wave row's patch
@@ -225,17 +274,47 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
     issue_w(st3, 0, blk);
     issue_w(st3, 1, blk);
   };
-  // M(cc, t): 16 back-to-back MFMAs
-  auto mma = [&]() {
+  // M(cc, t): 16 back-to-back MFMAs.  With a fused input GroupNorm, taps 3..6 also transform halo piece t - 3 of the next
+  // half-slice (landed: its load was issued in L(cc, t - 3) and retired by this wave's counted wait two phases later); the
+  // ~40 VALU / LDS instructions are spread between the MFMAs (sched_group_barrier), where the wave has free issue slots.
+  auto mma = [&](int cc, int t) {
     __builtin_amdgcn_s_setprio(1);
+    // (unconditional on the last half-slice too: it then rewrites the re-read copy in the buffer nobody reads any more)
+    const bool xf = gn_in && t >= 3 && t < 3 + NPIECE;
+    if (xf) {  // the five LDS reads go out first; their latency hides behind the first four MFMAs
+      gn_read(t - 3, cc + 1);
+      HP_SCHED_FENCE;
+    }
+    int n = 0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);  // D^T
+          if (xf && n == 3) {
+            HP_SCHED_FENCE;
+            gn_finish(t - 3, cc + 1);  // ~40 VALU + one LDS write, spread between the remaining MFMAs below
+          }
+          ++n;
+        }
+    if (xf) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // up to four VALU
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
+  };
+
+  // Tell the compiler's waitcnt pass that the fragments are complete HERE (it is called right after the explicit lgkmcnt(0)
+  // of the L segment): otherwise it inserts its own s_waitcnt lgkmcnt(0) at the first MFMA of the M segment, behind the
+  // GroupNorm transform's LDS reads issued there, and their latency is exposed again.
+  auto frags_ready = [&]() {
+    asm volatile("" ::"v"(fa[0][0]), "v"(fa[0][1]), "v"(fa[0][2]), "v"(fa[0][3]), "v"(fa[1][0]), "v"(fa[1][1]), "v"(fa[1][2]),
+                 "v"(fa[1][3]), "v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[1][0]), "v"(fb[1][1]));
   };
 
   // ---- prologue: halo of half-slice 0 and the weights of phases 0..2 ---------------------------------------------
@@ -252,7 +331,21 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   HP_WAITV(0);
   loads_on = false;
 #endif
+  if (gn_in) {  // (a, b) of both patches' segments -> LDS (plain loads: issued after the DMA queue, waited below)
+    for (int idx = tid; idx < 2 * Cin; idx += PNT) {
+      const int pch = idx >= Cin ? 1 : 0, ch = idx - pch * Cin;
+      const int seg = pch ? tl1.x : tl0.x;
+      *reinterpret_cast<float2*>(smem + COEF_OFF + idx * 8) = a.gn_coef[(size_t)seg * a.in_ld + goff + ch];
+    }
+  }
   HP_WAITV(4);  // halo + phase 0 landed (phases 1, 2 in flight)
+  if (gn_in) {
+    HP_WAITL();
+    HP_BAR();   // the coefficient table is complete for every wave
+#pragma unroll
+    for (int g = 0; g < NPIECE; ++g) gn_piece(g, 0);
+    HP_WAITL();
+  }
   HP_BAR();     // B_0
 
   // vmcnt immediates: a wave needs its loads of phase q+1 (issued in L(q-2)) landed before B_{2q+2}; the loads issued after
@@ -262,8 +355,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   HP_SCHED_FENCE;                         \
   issue_next(cc, t);                      \
   HP_WAITL();                             \
+  if (GNIN) frags_ready();                \
   HP_BAR();                               \
-  mma();                                  \
+  mma(cc, t);                             \
   HP_WAITV(nload((t) - 1) + nload(t));    \
   HP_BAR();
 #define HP_PHASE1(t)                      \
@@ -272,8 +366,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   issue_next(cc, t);                      \
   HP_WAITV(nload((t) - 1) + nload(t));    \
   HP_WAITL();                             \
+  if (GNIN) frags_ready();                \
   HP_BAR();                               \
-  mma();                                  \
+  mma(cc, t);                             \
   HP_BAR();
 
   if (wm == 0) {
@@ -409,6 +504,7 @@ int launch_hpipe_pack_weights(const void* w, void* out, int Cout, int Cin, hipSt
 }
 
 bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a) {
+  if (a.gn_coef && (a.Cin > COEF_MAX_CIN || a.group_cout > 0)) return false;
   return dt == DT_BF16 && !out_f32 && !a.stem && !a.in2 && a.res_mode == 0 && a.mul_nch == 0 && a.KH == 3 && a.KW == 3 &&
          a.stride == 1 && a.pad == 1 && (a.relu_nch == 0 || a.relu_nch >= a.Cout) && a.Cout % 256 == 0 && a.Cin % 32 == 0 &&
          a.Cin >= 32 && a.ss_padded_host && (a.out_ld & 7) == 0 && a.zeros != nullptr;
@@ -417,12 +513,14 @@ bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a) {
 int launch_conv_hpipe(const ConvArgs& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_hpipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
+    if (hipFuncSetAttribute((const void*)conv_hpipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
+    if (hipFuncSetAttribute((const void*)conv_hpipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
     attr_set = true;
   }
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  hipLaunchKernelGGL(conv_hpipe_kernel, dim3(grid), dim3(PNT), LDS_BYTES, s, a);
+  if (a.gn_coef) hipLaunchKernelGGL(conv_hpipe_kernel<true>, dim3(grid), dim3(PNT), LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(conv_hpipe_kernel<false>, dim3(grid), dim3(PNT), LDS_BYTES, s, a);
   return (int)hipGetLastError();
 }
 

@@ -371,6 +371,25 @@ int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg
   return (int)hipGetLastError();
 }
 
+// (mean, rstd) per (segment, group) + affine -> per (segment, channel) (a, b) with y = a * x + b (the apply pass of the NEXT
+// conv: conv_hpipe.hip transforms its input halo with these instead of a separate streaming pass over the tensor)
+__global__ void gn_coef_kernel(const float2* __restrict__ stats, int ngroups, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, float2* __restrict__ coef) {
+  const int seg = blockIdx.x, c = threadIdx.x, C = ngroups * 8;
+  if (c >= C) return;
+  const float2 st = stats[(size_t)seg * ngroups + (c >> 3)];
+  const float a = st.y * gamma[c];
+  coef[(size_t)seg * C + c] = make_float2(a, beta[c] - st.x * a);
+}
+
+int launch_gn_finalize_coef(int ngroups, const GnSeg* segs_dev, int nseg, const float* partial, float2* stats_ws, const float* gamma,
+                            const float* beta, float eps, float2* coef, hipStream_t s) {
+  if (ngroups != 32 && ngroups != 64) return -1;
+  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(1024), 0, s, segs_dev, ngroups, partial, eps, stats_ws);
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(nseg), dim3(ngroups * 8), 0, s, stats_ws, ngroups, gamma, beta, coef);
+  return (int)hipGetLastError();
+}
+
 int launch_groupnorm(DType dt, void* x, const RowSeg* segs_dev, int nseg, int max_rows, int ld, const float* gamma,
                      const float* beta, float eps, int relu, float* partial, float2* stats, hipStream_t s) {
   const int rpc = GN_ROWS_PER_CHUNK;

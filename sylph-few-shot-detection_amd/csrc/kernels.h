@@ -76,6 +76,8 @@ int launch_stem_conv(const void* x, const void* wp, const float* scale, const fl
 int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg* segs_dev, int nseg, int max_rows,
                              const float* partial, float2* stats_ws, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s);
+int launch_gn_finalize_coef(int ngroups, const GnSeg* segs_dev, int nseg, const float* partial, float2* stats_ws, const float* gamma,
+                            const float* beta, float eps, float2* coef, hipStream_t s);
 int launch_fill_random(DType dt, void* p, size_t n, unsigned seed, hipStream_t s);
 struct CopySeg { int src_row0, dst_row0, nrows; };
 int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg* segs_dev, int nseg, int max_rows,

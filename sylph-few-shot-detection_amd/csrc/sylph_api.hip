@@ -566,27 +566,35 @@ struct ConvOpts {
   const void* in2 = nullptr;  // dual-source pointwise conv: second input, its row stride / channels / stride
   int in2_ld = 0, Cin2 = 0, stride2 = 1;
   double flops = -1.0;     // algorithmic FLOPs of the launch when they differ from 2*M*N*K (stem padding)
+  const float2* gn_coef = nullptr;  // fused GroupNorm(+ReLU) of the INPUT (conv_hpipe.hip): (a, b) per (segment, input channel)
+  int gn_relu = 0;
 };
+
+// Will add_conv route this 3x3 layer to the deep-pipelined halo kernel (conv_hpipe.hip)?  MFMA-bound 3x3 stride-1 layers
+// with Cout % 256 == 0 (FCOS towers, FPN outputs, res4/res5 conv2) when its rounds fill the chip: at least two rounds over
+// the 256 CUs and >= 80 % of the last one used.
+static long patch_count(const std::vector<SegDesc>& segs, int max_pos, int halo_rows, int xpad);
+static bool use_hpipe(sylph_ctx* c, const ConvLayer& L, const std::vector<SegDesc>& segs, const ConvOpts& o) {
+  static const int hp_on = getenv("SYLPH_CONV_HPIPE") ? atoi(getenv("SYLPH_CONV_HPIPE")) : 1;
+  const int cout_l = o.cout_override >= 0 ? o.cout_override : L.Cout;
+  const bool k3s1 = L.KH == 3 && L.KW == 3 && o.stride == 1 && o.pad == 1 && !o.stem && !o.in2;
+  if (!(hp_on && k3s1 && c->dt == DT_BF16 && !o.out_f32 && !o.res && o.res_mode == 0 && o.mul_nch == 0 && o.cout_override < 0 &&
+        (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0 && L.Cout % 256 == 0 && L.Cout == L.Cout_pad))
+    return false;
+  const long blocks = (patch_count(segs, 128, 256, 4) + 1) / 2 * (L.Cout / 256), rounds = (blocks + 255) / 256;
+  return hp_on == 2 || (blocks >= 512 && blocks * 10 >= rounds * 256 * 8);
+}
 
 static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
                     int out_ld, const std::vector<SegDesc>& segs, const ConvOpts& o, Geom* geom_out = nullptr) {
   long rows = 0;
   for (auto& s : segs) rows += (long)s.out_H * s.out_W;
   int BM, BN;
-  const int cout_l = o.cout_override >= 0 ? o.cout_override : L.Cout;
   conv_pick_tile((int)rows, L.Cout_pad, o.stem ? 49 : L.KH * L.KW, &BM, &BN);
   if (L.Cout_pad % BN != 0) return fail("Cout_pad not a multiple of BN");
   const bool k3s1 = L.KH == 3 && L.KW == 3 && o.stride == 1 && o.pad == 1 && !o.stem && !o.in2;
-  // MFMA-bound 3x3 stride-1 layers with Cout % 256 == 0 (FCOS towers, FPN outputs, res4/res5 conv2): the deep-pipelined
-  // halo kernel (conv_hpipe.hip, one 256 x 256 tile = two patches per CU) when its rounds fill the chip: at least two
-  // rounds over the 256 CUs and >= 80 % of the last one used.
-  static const int hp_on = getenv("SYLPH_CONV_HPIPE") ? atoi(getenv("SYLPH_CONV_HPIPE")) : 1;
-  bool hpipe = false;
-  if (hp_on && k3s1 && c->dt == DT_BF16 && !o.out_f32 && !o.res && o.res_mode == 0 && o.mul_nch == 0 && o.cout_override < 0 &&
-      (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0 && L.Cout % 256 == 0 && L.Cout == L.Cout_pad) {
-    const long blocks = (patch_count(segs, 128, 256, 4) + 1) / 2 * (L.Cout / 256), rounds = (blocks + 255) / 256;
-    hpipe = hp_on == 2 || (blocks >= 512 && blocks * 10 >= rounds * 256 * 8);
-  }
+  const bool hpipe = use_hpipe(c, L, segs, o);
+  if (o.gn_coef && !hpipe) return fail("a fused input GroupNorm needs the conv_hpipe kernel (internal)");
   if (hpipe) { BM = 256; BN = 256; }
   // other 3x3 stride-1 convs on 128-row tiles: halo mode (input patch staged once per channel slice, 9 taps read it)
   static const int halo_on = getenv("SYLPH_CONV_HALO") ? atoi(getenv("SYLPH_CONV_HALO")) : 1;
@@ -624,6 +632,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   a.relu_nch = o.relu_nch; a.mul_nch = o.mul_nch; a.res_mode = o.res_mode;
   a.stem = o.stem; a.tap_dy = o.stem ? L.Cin / 32 : 1;
   a.group_cout = o.group_cout; a.group_in_off = o.group_in_off;
+  a.gn_coef = o.gn_coef; a.gn_relu = o.gn_relu;
   a.ss_padded = 1;  // ConvLayer scale/shift are zero-padded to Cout_pad
   if (o.in2) {
     a.in2 = o.in2; a.in2_ld = o.in2_ld; a.Cin2 = o.Cin2; a.stride2 = o.stride2;
@@ -642,8 +651,10 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
 }
 
 // conv + GroupNorm(32, 256)(+ReLU): statistics fused into the conv epilogue, one in-place apply pass
+// coef_out != nullptr: no apply pass; the (a, b) table of this layer's GroupNorm is left for the NEXT conv, which applies
+// it (+ ReLU) to its input halo in LDS (ConvOpts::gn_coef).
 static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
-                       const std::vector<SegDesc>& segs, ConvOpts o, const GNLayer& G, int relu) {
+                       const std::vector<SegDesc>& segs, ConvOpts o, const GNLayer& G, int relu, const float2** coef_out = nullptr) {
   o.want_gn = 1;
   Geom g;
   const int ld = L.Cout, ngroups = L.Cout / 8;
@@ -663,6 +674,13 @@ static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L,
   const float *ga = G.gamma, *be = G.beta;
   float2* stats_ws = nullptr;
   RET(c->dalloc((void**)&stats_ws, (size_t)nseg * ngroups * sizeof(float2)));
+  if (coef_out) {
+    float2* coef = nullptr;
+    RET(c->dalloc((void**)&coef, (size_t)nseg * ld * sizeof(float2)));
+    ops.push_back([=](hipStream_t s) { return launch_gn_finalize_coef(ngroups, gsd, nseg, partial, stats_ws, ga, be, 1e-5f, coef, s); });
+    *coef_out = coef;
+    return 0;
+  }
   ops.push_back([=](hipStream_t s) {
     return launch_gn_apply_partials(dt, out, ld, ngroups, gsd, nseg, max_rows, partial, stats_ws, ga, be, 1e-5f, relu, s);
   });
@@ -914,9 +932,20 @@ static int build_head(sylph_ctx* c, Plan* P) {
                    void** last) -> int {
     const void* in = P->F;
     void* out = b0;
+    // GroupNorm + ReLU of layers 0 .. n-2 are applied by the NEXT layer's conv to its input halo in LDS (conv_hpipe.hip):
+    // no separate streaming pass over those tensors.  The last layer keeps its apply pass (its readers are the
+    // prediction convs and the class-conditional 1x1 conv).
+    static const int gn_fuse_on = getenv("SYLPH_GN_FUSE") ? atoi(getenv("SYLPH_GN_FUSE")) : 1;
+    ConvOpts probe; probe.pad = 1;
+    const bool fuse = gn_fuse_on && convs.size() > 1 && convs[0].Cin <= 512 && use_hpipe(c, convs[1], segs, probe);
+    const float2* coef_prev = nullptr;
     for (size_t i = 0; i < convs.size(); ++i) {
       ConvOpts o; o.pad = 1;
-      RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1));
+      if (coef_prev) { o.gn_coef = coef_prev; o.gn_relu = 1; }
+      const float2* coef = nullptr;
+      const bool defer = fuse && i + 1 < convs.size();
+      RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1, defer ? &coef : nullptr));
+      coef_prev = coef;
       in = out;
       out = (out == b0) ? b1 : b0;
     }
@@ -2002,7 +2031,13 @@ int sylph_bench_conv(sylph_ctx* c, int B, int H, int W, int Cin, int Cout, int K
     KCHK(launch_fill_random(c->dt, res, nout, 2u, c->stream), "fill");
     o.res = res; o.res_ld = Cout; o.res_mode = 1;
   }
-  o.want_gn = with_gn;
+  o.want_gn = with_gn & 1;
+  if (with_gn & 2) {  // fused GroupNorm + ReLU of the input (conv_hpipe.hip): random (a, b) per (image, channel)
+    float2* coef;
+    RET(tmp.dalloc((void**)&coef, (size_t)B * Cin * sizeof(float2)));
+    KCHK(launch_fill_random(DT_F32, coef, (size_t)B * Cin * 2, 3u, c->stream), "fill");
+    o.gn_coef = coef; o.gn_relu = 1;
+  }
   std::vector<OpFn> ops;
   RET(add_conv(&tmp, ops, L, xin, Cin, yout, Cout, image_segs(B, H, W, Ho, Wo), o));
   for (int i = 0; i < 2; ++i) RET(run_ops(c, ops, "bench_conv"));

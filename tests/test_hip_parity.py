@@ -657,3 +657,24 @@ def test_c3_support_path_10_shot_full_size_bf16(full_sd):
     rc, rb = CG.normalize_code(ref["cls_conv"], ref["cls_bias"], full_sd)
     assert F.cosine_similarity(normed[0, :256], rc.reshape(-1), dim=0).item() > 0.99
     assert abs(normed[0, 256].item() - rb.item()) < 5e-2
+
+
+@pytest.mark.parametrize("tag", ["n5_t50", "n20_t50"])
+def test_head_bf16_close_to_reference_golden(g1, tag):
+    """The production (bf16) head -- conv_hpipe towers with the GroupNorm of layers 1-3 applied to the next conv's input
+    halo in LDS, when selected / forced -- against the reference golden: bf16 storage of 8 activation tensors deep gives
+    ~1e-2 relative deviations; bound measured on MI355X and asserted with margin."""
+    from sylph_amd import synthetic as W
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.head(torch.from_numpy(g1[f"{tag}_cls_conv"]), torch.from_numpy(g1[f"{tag}_cls_bias"]))
+    lo, rg, ct, io = eng.export_head()
+    worst = 0.0
+    for l in range(5):
+        for got, want in ((lo[l], g1[f"{tag}_logits{l}"]), (rg[l], g1[f"reg{l}"]), (ct[l], g1[f"ctr{l}"]), (io[l], g1[f"iou{l}"])):
+            err = np.abs(got.cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+            worst = max(worst, float(err))
+    print(f"bf16 head vs reference golden ({tag}): worst relative deviation {worst:.4f}")
+    assert worst < 4e-2, worst
