@@ -1,0 +1,392 @@
+// Fused ResNet identity bottleneck for the HBM-bound stage res2 (C = 256, mid = 64), bf16, WEIGHTS IN REGISTERS:
+//
+//     y = relu(x + bn3(conv1x1_{64->256}( relu(bn2(conv3x3_{64->64}( relu(bn1(conv1x1_{256->64}(x))) ))) )))
+//
+// (detectron2 BottleneckBlock with FrozenBN, stride 1, no projection: blocks 1.. of a stage; call site
+// sylph/modeling/meta_arch/meta_one_stage_detector.py:75,181,273.)  Unfused, the block moves 2 048 B per position through
+// HBM (x is read twice -- conv1 input and residual --, the two 64-channel intermediates are written and read back) and its
+// three launches sit at the 5.3-5.5 TB/s ceiling: 1.83 ms at B = 64.  Fused: x once, y once = 1 024 B per position.
+//
+// Two earlier fused designs (git history: "experiment: fused res2 identity bottleneck kernels") streamed the 136 KB of
+// weights through LDS for every 128-position tile: 17 small barrier-separated stages per tile made them sync / latency
+// bound (1.73 ms with two 4-wave blocks per CU, 2.27 ms persistent with one loader wave).  This kernel removes the weight
+// stream altogether:
+//
+//   * ONE persistent 256-thread block per CU, one wave per SIMD, so every lane may use up to 512 VGPRs.  Each wave loads, once,
+//     the MFMA weight fragments of the output channels it owns: W1 (its 32 of 64 mid channels, K 256: 64 VGPRs), W2 (the same
+//     32 channels, 9 taps x K 64: 144 VGPRs), W3 (its 64 of 256 output channels, K 64: 32 VGPRs).
+//   * LDS holds only activations: the x halo of the tile [192 rows][256 ch] (96 KiB, filled by global_load_lds; chunk swizzle
+//     c ^ (row & 31)), t1 / t2 (24 KiB, bf16) and the FrozenBN tables.  Four barriers per tile.
+//   * Right after conv1 has consumed the halo (and every lane has copied the 128 residual values of its conv3 outputs from it
+//     into registers), all waves issue the NEXT tile's halo: 96 KiB per CU in flight during conv2 / conv3 -- enough to cover
+//     the HBM latency at the CU's bandwidth share, which the two-block design could not.
+//   * conv3 epilogue in registers (D^T MFMA layout: a lane owns 4 consecutive channels of a position): bn3 + residual + ReLU ->
+//     bf16, 8-byte stores; a wave writes complete 128-byte lines of a position within eight consecutive stores.
+//
+// P1 recomputes conv1 on the (ph+2) x (pw+2) halo (+40 % of its flops); halo positions outside the image are forced to 0
+// (they are conv2's zero padding).  P2 reads shifted rows of the t1 halo exactly like conv_igemm.hip's HALO mode.
+#include "common.h"
+
+namespace sylph {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+namespace {
+constexpr int MID = 64, C = 256;
+constexpr int XROWS = 192;
+constexpr int XB_BYTES = XROWS * 512;          // 98 304: x halo
+constexpr int T1_OFF = XB_BYTES;               // 24 576: t1 halo [192][64 ch]; t2 [128][64 ch] aliases it
+constexpr int BN_OFF = T1_OFF + XROWS * 128;   // s1 b1 s2 b2 (64 each) s3 b3 (256 each), fp32
+constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 125 952
+
+// MFMA with the weight fragment read straight from an AGPR and the accumulator in arch VGPRs.  Through the builtin hipcc keeps
+// weights and accumulators in AGPRs only as spill space and pays a v_accvgpr_read per use (~450 per tile, all on the one wave
+// that also has to issue the MFMAs).  Inline asm is invisible to the hazard recogniser: BK_MFMA_DRAIN* before the first VALU
+// read of an accumulator supplies the wait states (16-pass MFMA: 18) it would have inserted.
+#define BK_MFMA(acc, w, av) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(av))
+// first k-step of a chain: srcC = 0 (a VALU zero-fill followed by an MFMA reading it is a 2-wait-state hazard nobody would pad)
+#define BK_MFMA0(acc, w, av) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(av))
+// (the accumulators are operands of the drain: their VALU reads must not be scheduled above it)
+#define BK_MFMA_DRAIN2(a0, a1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1)::"memory")
+#define BK_MFMA_DRAIN3(a0, a1, a2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2)::"memory")
+
+#ifdef BK_NOBAR
+#define BK_BAR() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define BK_BAR()                                       \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                      \
+    asm volatile("" ::: "memory");                     \
+  } while (0)
+#endif
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckArgs a) {
+  typedef bf16_t T;
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));  // ext_vector LDS accesses: hipcc adds no vmcnt(0) for them beside LDS-DMA
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ zero = reinterpret_cast<const T*>(a.zeros);
+  T* __restrict__ y = reinterpret_cast<T*>(a.y);
+  char* const xb = smem;
+  char* const t1 = smem + T1_OFF;
+  float* const bn = reinterpret_cast<float*>(smem + BN_OFF);
+
+  // ---- weights -> registers (plain loads, before any LDS-DMA exists) -------------------------------------------------------
+  const int ct1 = wave >> 1;  // P1 / P2: this wave's 32 mid channels
+  bf16x8 W1f[16], W2f[36], W3f[2][4];
+  {
+    const T* w1p = a.w1 + ((ct1 * 32 + l31) * C + lh * 8);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) W1f[ks] = *reinterpret_cast<const bf16x8*>(w1p + ks * 16);
+    const T* w2p = a.w2 + ((ct1 * 32 + l31) * 9 * MID + lh * 8);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) W2f[k] = *reinterpret_cast<const bf16x8*>(w2p + k * 16);  // tap * 64 + ks * 16 == k * 16
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const T* w3p = a.w3 + (((2 * wave + j) * 32 + l31) * MID + lh * 8);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) W3f[j][ks] = *reinterpret_cast<const bf16x8*>(w3p + ks * 16);
+    }
+  }
+  for (int i = tid; i < 4 * MID + 2 * C; i += 256) {
+    const float* src = i < MID ? a.s1 + i : i < 2 * MID ? a.b1 + (i - MID) : i < 3 * MID ? a.s2 + (i - 2 * MID)
+                     : i < 4 * MID ? a.b2 + (i - 3 * MID) : i < 4 * MID + C ? a.s3 + (i - 4 * MID) : a.b3 + (i - 4 * MID - C);
+    bn[i] = *src;
+  }
+  const float *s1 = bn, *b1 = bn + MID, *s2 = bn + 2 * MID, *b2 = bn + 3 * MID, *s3 = bn + 4 * MID, *b3 = bn + 4 * MID + C;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // persistent tile walk: blocks of one XCD (blockIdx & 7) take neighbouring patches at the same time
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, gx = (G + 7) >> 3;
+  const int chunk = (a.n_tiles + 7) >> 3;
+  auto tile_of = [&](int it) { const int q = it * gx + jb; return __builtin_amdgcn_readfirstlane(q < chunk ? xcd * chunk + q : a.n_tiles); };
+  // tile descriptor through the SCALAR cache (a vector load would put a vmcnt(0) into the stream; hipcc will not use s_load
+  // for memory it cannot prove read-only)
+  auto load_tile = [&](int t) {
+    i32x8 v;
+    const BkTile* p = a.bk + t;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+  };
+  // x halo -> LDS: 24 rounds of 8 rows x 512 B; slot s of row r holds 16-byte chunk s ^ (r & 31)
+  const int xr = tid >> 5, xs = tid & 31;
+  auto issue_x = [&](const i32x8 d) {
+    const int row0 = d[0], H = d[1], W = d[2], oy0 = d[3] >> 16, ox0 = d[3] & 0xffff, HW2 = d[5] + 2, HR = (d[4] + 2) * HW2;
+    const unsigned inv_hw2 = (unsigned)d[7];
+#pragma unroll 4
+    for (int r = 0; r < 24; ++r) {
+      const int h = r * 8 + xr;
+      const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const bool ok = h < HR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const T* src = ok ? x + ((size_t)(row0 + iy * W + ix) * C + (xs ^ (h & 31)) * 8) : zero + (xs & 3) * 8;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xb + r * 4096 + wave * 1024), 16, 0, 0);
+    }
+  };
+
+  int t = tile_of(0);
+  i32x8 td = load_tile(t < a.n_tiles ? t : 0);
+  if (t < a.n_tiles) issue_x(td);
+  const int rb1 = (wave & 1) * 3, rb2 = (wave & 1) * 2;  // first row tile of this wave in P1 (3 tiles) / P2 (2 tiles)
+
+  for (int it = 0; t < a.n_tiles; ++it) {
+    const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
+    const int PW = td[5], HW2 = PW + 2, HR = (td[4] + 2) * HW2, NPOS = td[4] * PW;
+    const unsigned inv_pw = (unsigned)td[6], inv_hw2 = (unsigned)td[7];
+    const int t_next = tile_of(it + 1);
+    const i32x8 td_next = load_tile(t_next < a.n_tiles ? t_next : 0);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's halo has landed (and the previous tile's stores are out)
+    BK_BAR();                                         // ... for every wave; t1 / t2 of the previous tile are free
+
+    // ===== P1: t1 = relu(bn1(x_halo . W1^T)), row tiles rb1 .. rb1+2, channels ct1 ===========================================
+    // (lz*: zero, opaque to the compiler and re-made per tile and phase: the swizzled LDS addresses below would otherwise be
+    //  hoisted out of the tile loop as ~150 loop-invariant VGPRs, leaving no registers to pipeline the fragment reads)
+    {
+      int lz1;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lz1));
+      const int l31a = l31 + lz1;
+      f32x16 acc1[3];
+      const char* arow[3];
+      int akey[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int row = (rb1 + i) * 32 + l31a;
+        arow[i] = xb + row * 512;
+        akey[i] = (row & 31) ^ lh;
+      }
+      constexpr int D1 = 3;  // fragment ring: reads run D1 - 1 k-steps ahead of the MFMAs (one wave per SIMD: nothing else hides LDS latency)
+      bf16x8 af[D1][3];
+#pragma unroll
+      for (int ks = 0; ks < D1 - 1; ++ks)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(arow[i] + (((ks * 2) ^ akey[i]) << 4));
+      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (D1 - 1), 0);
+#ifdef BK_NOP1
+      constexpr int K1 = 4;
+#else
+      constexpr int K1 = 16;
+#endif
+#pragma unroll
+      for (int ks = 0; ks < K1; ++ks) {
+        if (ks + D1 - 1 < 16) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            af[(ks + D1 - 1) % D1][i] = *reinterpret_cast<const bf16x8*>(arow[i] + ((((ks + D1 - 1) * 2) ^ akey[i]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (ks == 0) BK_MFMA0(acc1[i], W1f[ks], af[ks % D1][i]);
+          else BK_MFMA(acc1[i], W1f[ks], af[ks % D1][i]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // keep the reads AHEAD of the MFMAs they do not feed (the
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // pressure-driven scheduler otherwise sinks each read to its use)
+      }
+      BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int h = (rb1 + i) * 32 + l31a;
+        const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
+        const bool in1 = h < HR && (unsigned)(oy0 - 1 + hy) < (unsigned)IH && (unsigned)(ox0 - 1 + hx) < (unsigned)IW;
+        const int sw1 = ((hy * PW + hx) >> 1) & 7;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n0 = ct1 * 32 + 8 * gq + 4 * lh;
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + n0), bv = *reinterpret_cast<const f32x4*>(b1 + n0);
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc1[i][4 * gq + e] * sv[e] + bv[e];
+            v = (v > 0.f && in1) ? v : 0.f;
+            o[e] = (bf16_t)v;
+          }
+          *reinterpret_cast<bf16x4*>(t1 + h * 128 + (((ct1 * 4 + gq) ^ sw1) << 4) + 8 * lh) = o;
+        }
+      }
+    }
+    // residual values of this lane's conv3 outputs (positions rt * 32 + l31, channels 64 wave + 32 j + 8 gq + 4 lh ..): halo -> registers
+    u32x2 res[32];
+    int ypos[4];
+    bool pv[4];
+    int lzr;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lzr));
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int m = rt * 32 + l31 + lzr;
+      const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
+      pv[rt] = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
+      ypos[rt] = (row0 + (oy0 + my) * IW + ox0 + mx) * C;
+      const int hc = (my + 1) * HW2 + mx + 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int cch = 8 * wave + 4 * j + gq;
+          res[rt * 8 + j * 4 + gq] = *reinterpret_cast<const u32x2*>(xb + hc * 512 + ((cch ^ (hc & 31)) << 4) + 8 * lh);
+        }
+    }
+    // (re-defined through asm: hipcc would otherwise tie their first use to vmcnt(0), they come from the LDS-DMA target)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]),
+                   "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
+    asm volatile(""
+                 : "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]), "+v"(res[20]), "+v"(res[21]), "+v"(res[22]), "+v"(res[23]),
+                   "+v"(res[24]), "+v"(res[25]), "+v"(res[26]), "+v"(res[27]), "+v"(res[28]), "+v"(res[29]), "+v"(res[30]), "+v"(res[31]));
+    BK_BAR();  // t1 complete; every wave is done with the x halo
+#ifndef BK_NOX
+    if (t_next < a.n_tiles) issue_x(td_next);
+#endif
+
+    // ===== P2: t2 = relu(bn2(conv3x3(t1))), row tiles rb2, rb2+1, channels ct1 ===============================================
+    {
+      int lz2;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lz2));
+      const int l31b = l31 + lz2;
+      f32x16 acc2[2];
+      const char* hrow[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = (rb2 + i) * 32 + l31b;
+        const int my = (int)(((unsigned)m * inv_pw) >> 16);
+        hrow[i] = t1 + (my * HW2 + (m - my * PW)) * 128;
+      }
+      // k-step k = tap * 4 + ks; fragment address = hrow + tap offset + swizzled chunk
+      auto p2_off = [&](int k) {
+        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
+        const int asw = ((l31b + kh * PW + kw) >> 1) & 7;
+        return (kh * HW2 + kw) * 128 + (((ks * 2 + lh) ^ asw) << 4);
+      };
+      constexpr int D2 = 4;
+      bf16x8 af[D2][2];
+#pragma unroll
+      for (int k = 0; k < D2 - 1; ++k) {
+        const int off = p2_off(k);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[k][i] = *reinterpret_cast<const bf16x8*>(hrow[i] + off);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D2 - 1), 0);
+#ifdef BK_NOP2
+      constexpr int K2 = 8;
+#else
+      constexpr int K2 = 36;
+#endif
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        if (k + D2 - 1 < 36) {
+          const int off = p2_off(k + D2 - 1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[(k + D2 - 1) % D2][i] = *reinterpret_cast<const bf16x8*>(hrow[i] + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
+          else BK_MFMA(acc2[i], W2f[k], af[k % D2][i]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+      BK_MFMA_DRAIN2(acc2[0], acc2[1]);
+      BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = (rb2 + i) * 32 + l31b;
+        const int msw = (m >> 1) & 7;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n0 = ct1 * 32 + 8 * gq + 4 * lh;
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(s2 + n0), bv = *reinterpret_cast<const f32x4*>(b2 + n0);
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc2[i][4 * gq + e] * sv[e] + bv[e];
+            o[e] = (bf16_t)(v > 0.f ? v : 0.f);
+          }
+          *reinterpret_cast<bf16x4*>(t1 + m * 128 + (((ct1 * 4 + gq) ^ msw) << 4) + 8 * lh) = o;
+        }
+      }
+    }
+    BK_BAR();  // t2 complete
+
+    // ===== P3: y = relu(bn3(t2 . W3^T) + x), all four row tiles, channels 64 wave .. 64 wave + 63 ==========================
+    {
+      int lz3;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lz3));
+      const int l31c = l31 + lz3;
+      const int swz8 = (l31c >> 1) & 7;
+      bf16x8 av[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) av[0][ks] = *reinterpret_cast<const bf16x8*>(t1 + l31c * 128 + (((ks * 2 + lh) ^ swz8) << 4));
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        if (rt < 3) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            av[(rt + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(t1 + ((rt + 1) * 32 + l31c) * 128 + (((ks * 2 + lh) ^ swz8) << 4));
+        }
+        f32x16 acc3[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          BK_MFMA0(acc3[j], W3f[j][0], av[rt & 1][0]);
+#pragma unroll
+          for (int ks = 1; ks < 4; ++ks) BK_MFMA(acc3[j], W3f[j][ks], av[rt & 1][ks]);
+        }
+        BK_MFMA_DRAIN2(acc3[0], acc3[1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int n0 = 64 * wave + 32 * j + 8 * gq + 4 * lh;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(s3 + n0), bv = *reinterpret_cast<const f32x4*>(b3 + n0);
+            const u32x2 rv = res[rt * 8 + j * 4 + gq];
+            const float r4[4] = {__uint_as_float(rv[0] << 16), __uint_as_float(rv[0] & 0xffff0000u), __uint_as_float(rv[1] << 16),
+                                 __uint_as_float(rv[1] & 0xffff0000u)};
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#ifdef BK_NOE3
+              o[e] = (bf16_t)(acc3[j][4 * gq + e] + (e == 0 ? sv[0] + bv[0] + r4[0] : 0.f));
+#else
+              const float v = acc3[j][4 * gq + e] * sv[e] + bv[e] + r4[e];
+              o[e] = (bf16_t)(v > 0.f ? v : 0.f);
+#endif
+            }
+#ifdef BK_NOSTORE
+            if (pv[rt] && o[0] == (bf16_t)1234.5f) *reinterpret_cast<bf16x4*>(y + ypos[rt] + n0) = o;
+#else
+            if (pv[rt]) *reinterpret_cast<bf16x4*>(y + ypos[rt] + n0) = o;
+#endif
+          }
+      }
+    }
+    t = t_next;
+    td = td_next;
+  }
+}
+
+int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  static int ncu = 256;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)bottleneck64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  // the tile walk pairs blockIdx & 7 (XCD) with blockIdx >> 3: the grid must be a whole number of 8-block rounds
+  const int want = (a.n_tiles + 7) & ~7;
+  const int grid = want < ncu ? want : (ncu & ~7);
+  hipLaunchKernelGGL(bottleneck64_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace sylph

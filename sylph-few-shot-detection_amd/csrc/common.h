@@ -58,6 +58,19 @@ struct ConvArgs {
   int gn_relu;                //   x <- relu?(a * x + b) applied to the landed halo in LDS; row stride of gn_coef = in_ld
 };
 
+// fused identity bottleneck (bottleneck.hip): x, y [pos][256] bf16; w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16
+// (the conv_igemm weight layouts); FrozenBN scale / shift per conv (fp32)
+struct BkTile { int row0, H, W, yx, ph, pw; unsigned inv_pw, inv_hw2; };  // one 32-byte descriptor per patch (s_load_dwordx8)
+struct BottleneckArgs {
+  const void* x;
+  void* y;
+  const __bf16 *w1, *w2, *w3;
+  const float *s1, *b1, *s2, *b2, *s3, *b3;
+  const void* zeros;
+  const BkTile* bk;
+  int n_tiles;
+};
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
   static __device__ __forceinline__ float to_f(float v) { return v; }
@@ -113,6 +126,7 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
 bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a);
 int launch_conv_hpipe(const ConvArgs& a, hipStream_t s);
 int launch_hpipe_pack_weights(const void* w_igemm, void* w_hpipe, int Cout, int Cin, hipStream_t s);  // a.wt of an hpipe launch
+int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s);  // bottleneck.hip: persistent, weights in registers
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 
 }  // namespace sylph

@@ -798,6 +798,35 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
       const int H1 = (Hin - 1) / s1 + 1, W1 = (Win - 1) / s1 + 1;
       const int Ho = (Hin - 1) / stride + 1, Wo = (Win - 1) / stride + 1;
       Y = (Y == Ya) ? Yb : Ya;
+      // res2 identity blocks (C 256, mid 64, stride 1, no projection), bf16: ONE fused kernel (bottleneck.hip): the two
+      // 64-channel intermediates and the second read of x never reach HBM (2 048 -> 1 024 B per position)
+      static const int fuse_bn = getenv("SYLPH_FUSE_BOTTLENECK") ? atoi(getenv("SYLPH_FUSE_BOTTLENECK")) : 1;
+      if (fuse_bn && dt == DT_BF16 && !blk.has_sc && stride == 1 && mid == 64 && Cin == 256 && cout == 256 &&
+          blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3.Cout_pad == 256) {
+        BottleneckArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.x = X; ba.y = Y;
+        ba.w1 = (const __bf16*)blk.c1.w; ba.w2 = (const __bf16*)blk.c2.w; ba.w3 = (const __bf16*)blk.c3.w;
+        ba.s1 = blk.c1.scale; ba.b1 = blk.c1.shift; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
+        ba.s3 = blk.c3.scale; ba.b3 = blk.c3.shift;
+        ba.zeros = c->zeros;
+        std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
+        std::vector<BkTile> bt;
+        int ph, pw;
+        pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
+        for (size_t si2 = 0; si2 < sg.size(); ++si2)
+          for (int yy = 0; yy < Hin; yy += ph)
+            for (int xx = 0; xx < Win; xx += pw)
+              bt.push_back(BkTile{sg[si2].in_row0, Hin, Win, (yy << 16) | xx, ph, pw, (65536u + pw - 1) / pw, (65536u + pw + 2 - 1) / (pw + 2)});
+        void* btd = nullptr;
+        RET(upload(c, &btd, bt.data(), bt.size() * sizeof(BkTile)));
+        ba.bk = (const BkTile*)btd;
+        ba.n_tiles = (int)bt.size();
+        const double fl = 2.0 * (double)B * Hin * Win * (256.0 * 64 + 64.0 * 576 + 64.0 * 256);
+        ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64(ba, st); }); });
+        X = Y;
+        continue;
+      }
       ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
       RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
       ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
