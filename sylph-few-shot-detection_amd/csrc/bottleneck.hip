@@ -36,9 +36,10 @@ namespace {
 constexpr int MID = 64, C = 256;
 constexpr int XROWS = 192;
 constexpr int XB_BYTES = XROWS * 512;          // 98 304: x halo
-constexpr int T1_OFF = XB_BYTES;               // 24 576: t1 halo [192][64 ch]; t2 [128][64 ch] aliases it
-constexpr int BN_OFF = T1_OFF + XROWS * 128;   // s1 b1 s2 b2 (64 each) s3 b3 (256 each), fp32
-constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 125 952
+constexpr int TP = 144;                        // t1 / t2 row pitch: 128 B of channels + 16 B pad (bank-conflict-free, no swizzle)
+constexpr int T1_OFF = XB_BYTES;               // 27 648: t1 halo [192][64 ch]; t2 [128][64 ch] aliases it
+constexpr int BN_OFF = T1_OFF + XROWS * TP;    // s1 b1 s2 b2 (64 each) s3 b3 (256 each), fp32
+constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 
 // MFMA with the weight fragment read straight from an AGPR and the accumulator in arch VGPRs.  Through the builtin hipcc keeps
 // weights and accumulators in AGPRs only as spill space and pays a v_accvgpr_read per use (~450 per tile, all on the one wave
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ zero = reinterpret_cast<const T*>(a.zeros);
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
+  char* const trash = reinterpret_cast<char*>(a.trash) + ((size_t)blockIdx.x * 256 + tid) * 128;  // 128 B per thread: the 8 stores of a row tile
   char* const xb = smem;
   char* const t1 = smem + T1_OFF;
   float* const bn = reinterpret_cast<float*>(smem + BN_OFF);
@@ -116,19 +117,21 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
     return v;
   };
-  // x halo -> LDS: 24 rounds of 8 rows x 512 B; slot s of row r holds 16-byte chunk s ^ (r & 31)
+  // x halo -> LDS: rounds of 8 rows x 512 B; slot s of row r holds 16-byte chunk s ^ (r & 31).  Halo rows outside the image
+  // are loaded from a clamped (valid) address instead of a zero page: whatever lands there is never used -- P1 masks t1 to 0
+  // for those rows (they are conv2's zero padding) and the residual is only read at stored positions.
   const int xr = tid >> 5, xs = tid & 31;
   auto issue_x = [&](const i32x8 d) {
     const int row0 = d[0], H = d[1], W = d[2], oy0 = d[3] >> 16, ox0 = d[3] & 0xffff, HW2 = d[5] + 2, HR = (d[4] + 2) * HW2;
-    const unsigned inv_hw2 = (unsigned)d[7];
-#pragma unroll 4
-    for (int r = 0; r < 24; ++r) {
+    const int nr = (HR + 7) >> 3;  // rows >= HR are never read by P2
+    int hy = 0, hx = xr;           // xr < 8 <= HW2
+    for (int r = 0; r < nr; ++r) {
       const int h = r * 8 + xr;
-      const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      const bool ok = h < HR && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const T* src = ok ? x + ((size_t)(row0 + iy * W + ix) * C + (xs ^ (h & 31)) * 8) : zero + (xs & 3) * 8;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(xb + r * 4096 + wave * 1024), 16, 0, 0);
+      const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
+      const unsigned off = ((unsigned)(row0 + iy * W + ix) << 9) + (unsigned)((xs ^ (h & 31)) << 4);  // bytes; x < 4 GiB (checked by the host)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(xb + r * 4096 + wave * 1024), 16, 0, 0);
+      hx += 8;
+      if (hx >= HW2) { hx -= HW2; ++hy; }
     }
   };
 
@@ -136,6 +139,20 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   i32x8 td = load_tile(t < a.n_tiles ? t : 0);
   if (t < a.n_tiles) issue_x(td);
   const int rb1 = (wave & 1) * 3, rb2 = (wave & 1) * 2;  // first row tile of this wave in P1 (3 tiles) / P2 (2 tiles)
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  // bf16 pair: ReLU as a packed signed-16-bit max with 0 (sign bit set <=> negative), then AND with a keep mask
+  auto relu_pk = [](unsigned u, unsigned keep) {
+    const s16x2 z = {0, 0};
+    const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), z);
+    return __builtin_bit_cast(unsigned, r) & keep;
+  };
+  auto pack2 = [](float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (bf16_t)lo;
+    v[1] = (bf16_t)hi;
+    return __builtin_bit_cast(unsigned, v);
+  };
 
   for (int it = 0; t < a.n_tiles; ++it) {
     const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
@@ -144,31 +161,33 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     const int t_next = tile_of(it + 1);
     const i32x8 td_next = load_tile(t_next < a.n_tiles ? t_next : 0);
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's halo has landed (and the previous tile's stores are out)
-    BK_BAR();                                         // ... for every wave; t1 / t2 of the previous tile are free
+    // this tile's halo has landed.  The counter retires in issue order and every lane issues exactly 32 stores per tile AFTER
+    // the halo loads of the next one (lanes without a valid position write to a private trash slot instead of being masked
+    // off), so vmcnt(32) leaves the previous tile's stores -- and their ~2 us of write acknowledgement -- in flight
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    BK_BAR();  // ... for every wave; t1 / t2 of the previous tile are free
 
     // ===== P1: t1 = relu(bn1(x_halo . W1^T)), row tiles rb1 .. rb1+2, channels ct1 ===========================================
-    // (lz*: zero, opaque to the compiler and re-made per tile and phase: the swizzled LDS addresses below would otherwise be
-    //  hoisted out of the tile loop as ~150 loop-invariant VGPRs, leaving no registers to pipeline the fragment reads)
+    // (lz*: zero, opaque to the compiler and re-made per tile and phase: LDS addresses would otherwise be hoisted out of the tile
+    //  loop as ~150 loop-invariant VGPRs, leaving no registers to pipeline the fragment reads)
     {
       int lz1;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz1));
       const int l31a = l31 + lz1;
       f32x16 acc1[3];
-      const char* arow[3];
-      int akey[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int row = (rb1 + i) * 32 + l31a;
-        arow[i] = xb + row * 512;
-        akey[i] = (row & 31) ^ lh;
-      }
+      // the three row tiles are 32 rows = 16 KiB apart and share the swizzle key (row & 31 == l31): one address per k-step,
+      // the tiles are immediate offsets
+      const char* abase = xb + (rb1 * 32 + l31a) * 512;
+      const int akey = (l31a ^ lh) << 4;
       constexpr int D1 = 3;  // fragment ring: reads run D1 - 1 k-steps ahead of the MFMAs (one wave per SIMD: nothing else hides LDS latency)
       bf16x8 af[D1][3];
 #pragma unroll
-      for (int ks = 0; ks < D1 - 1; ++ks)
+      for (int ks = 0; ks < D1 - 1; ++ks) {
+        const char* ap = abase + ((ks * 32) ^ akey);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(arow[i] + (((ks * 2) ^ akey[i]) << 4));
+        for (int i = 0; i < 3; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16384);
+      }
       __builtin_amdgcn_sched_group_barrier(0x100, 3 * (D1 - 1), 0);
 #ifdef BK_NOP1
       constexpr int K1 = 4;
@@ -178,60 +197,53 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 #pragma unroll
       for (int ks = 0; ks < K1; ++ks) {
         if (ks + D1 - 1 < 16) {
+          const char* ap = abase + (((ks + D1 - 1) * 32) ^ akey);
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
-            af[(ks + D1 - 1) % D1][i] = *reinterpret_cast<const bf16x8*>(arow[i] + ((((ks + D1 - 1) * 2) ^ akey[i]) << 4));
+          for (int i = 0; i < 3; ++i) af[(ks + D1 - 1) % D1][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16384);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           if (ks == 0) BK_MFMA0(acc1[i], W1f[ks], af[ks % D1][i]);
           else BK_MFMA(acc1[i], W1f[ks], af[ks % D1][i]);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // keep the reads AHEAD of the MFMAs they do not feed (the
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // pressure-driven scheduler otherwise sinks each read to its use)
       }
       BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
+      const float* sp = s1 + ct1 * 32 + 4 * lh;  // b1 = s1 + 64
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int h = (rb1 + i) * 32 + l31a;
         const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
         const bool in1 = h < HR && (unsigned)(oy0 - 1 + hy) < (unsigned)IH && (unsigned)(ox0 - 1 + hx) < (unsigned)IW;
-        const int sw1 = ((hy * PW + hx) >> 1) & 7;
+        const unsigned keep = in1 ? 0xffffffffu : 0u;
+        char* wp = t1 + h * TP + ct1 * 64 + 8 * lh;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const int n0 = ct1 * 32 + 8 * gq + 4 * lh;
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(s1 + n0), bv = *reinterpret_cast<const f32x4*>(b1 + n0);
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc1[i][4 * gq + e] * sv[e] + bv[e];
-            v = (v > 0.f && in1) ? v : 0.f;
-            o[e] = (bf16_t)v;
-          }
-          *reinterpret_cast<bf16x4*>(t1 + h * 128 + (((ct1 * 4 + gq) ^ sw1) << 4) + 8 * lh) = o;
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + MID + 8 * gq);
+          u32x2 o;
+          o[0] = relu_pk(pack2(acc1[i][4 * gq] * sv[0] + bv[0], acc1[i][4 * gq + 1] * sv[1] + bv[1]), keep);
+          o[1] = relu_pk(pack2(acc1[i][4 * gq + 2] * sv[2] + bv[2], acc1[i][4 * gq + 3] * sv[3] + bv[3]), keep);
+          *reinterpret_cast<u32x2*>(wp + gq * 16) = o;
         }
       }
     }
     // residual values of this lane's conv3 outputs (positions rt * 32 + l31, channels 64 wave + 32 j + 8 gq + 4 lh ..): halo -> registers
     u32x2 res[32];
-    int ypos[4];
-    bool pv[4];
+    char* yptr[4];
     int lzr;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lzr));
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       const int m = rt * 32 + l31 + lzr;
       const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
-      pv[rt] = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
-      ypos[rt] = (row0 + (oy0 + my) * IW + ox0 + mx) * C;
+      const bool pv = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
+      yptr[rt] = pv ? reinterpret_cast<char*>(y) + ((size_t)(unsigned)(row0 + (oy0 + my) * IW + ox0 + mx) * (C * 2) + 128 * wave + 8 * lh) : trash;
       const int hc = (my + 1) * HW2 + mx + 1;
+      const int rowoff = hc * 512 + ((hc & 31) << 4) + 8 * lh;  // chunk c of this row sits at rowoff ^ (c << 4)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int cch = 8 * wave + 4 * j + gq;
-          res[rt * 8 + j * 4 + gq] = *reinterpret_cast<const u32x2*>(xb + hc * 512 + ((cch ^ (hc & 31)) << 4) + 8 * lh);
-        }
+        for (int gq = 0; gq < 4; ++gq)
+          res[rt * 8 + j * 4 + gq] = *reinterpret_cast<const u32x2*>(xb + (rowoff ^ ((8 * wave + 4 * j + gq) << 4)));
     }
     // (re-defined through asm: hipcc would otherwise tie their first use to vmcnt(0), they come from the LDS-DMA target)
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -246,6 +258,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 #endif
 
     // ===== P2: t2 = relu(bn2(conv3x3(t1))), row tiles rb2, rb2+1, channels ct1 ===============================================
+    // t1 / t2 rows are PADDED to 144 B (they are written by ds_write, not by DMA): conflict-free without a swizzle, so the
+    // k-step and tile offsets of every read are instruction immediates (one VALU add per tap and tile instead of per read)
     {
       int lz2;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz2));
@@ -256,22 +270,18 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       for (int i = 0; i < 2; ++i) {
         const int m = (rb2 + i) * 32 + l31b;
         const int my = (int)(((unsigned)m * inv_pw) >> 16);
-        hrow[i] = t1 + (my * HW2 + (m - my * PW)) * 128;
+        hrow[i] = t1 + (my * HW2 + (m - my * PW)) * TP + 16 * lh;
       }
-      // k-step k = tap * 4 + ks; fragment address = hrow + tap offset + swizzled chunk
-      auto p2_off = [&](int k) {
+      auto p2_ptr = [&](int k, int i) {  // k-step k = tap * 4 + ks
         const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
-        const int asw = ((l31b + kh * PW + kw) >> 1) & 7;
-        return (kh * HW2 + kw) * 128 + (((ks * 2 + lh) ^ asw) << 4);
+        return reinterpret_cast<const bf16x8*>(hrow[i] + (kh * HW2 + kw) * TP + ks * 32);
       };
       constexpr int D2 = 4;
       bf16x8 af[D2][2];
 #pragma unroll
-      for (int k = 0; k < D2 - 1; ++k) {
-        const int off = p2_off(k);
+      for (int k = 0; k < D2 - 1; ++k)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[k][i] = *reinterpret_cast<const bf16x8*>(hrow[i] + off);
-      }
+        for (int i = 0; i < 2; ++i) af[k][i] = *p2_ptr(k, i);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D2 - 1), 0);
 #ifdef BK_NOP2
       constexpr int K2 = 8;
@@ -281,35 +291,28 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 #pragma unroll
       for (int k = 0; k < K2; ++k) {
         if (k + D2 - 1 < 36) {
-          const int off = p2_off(k + D2 - 1);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) af[(k + D2 - 1) % D2][i] = *reinterpret_cast<const bf16x8*>(hrow[i] + off);
+          for (int i = 0; i < 2; ++i) af[(k + D2 - 1) % D2][i] = *p2_ptr(k + D2 - 1, i);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
           else BK_MFMA(acc2[i], W2f[k], af[k % D2][i]);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       }
       BK_MFMA_DRAIN2(acc2[0], acc2[1]);
       BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
+      const float* sp = s2 + ct1 * 32 + 4 * lh;  // b2 = s2 + 64
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int m = (rb2 + i) * 32 + l31b;
-        const int msw = (m >> 1) & 7;
+        char* wp = t1 + ((rb2 + i) * 32 + l31b) * TP + ct1 * 64 + 8 * lh;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const int n0 = ct1 * 32 + 8 * gq + 4 * lh;
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(s2 + n0), bv = *reinterpret_cast<const f32x4*>(b2 + n0);
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = acc2[i][4 * gq + e] * sv[e] + bv[e];
-            o[e] = (bf16_t)(v > 0.f ? v : 0.f);
-          }
-          *reinterpret_cast<bf16x4*>(t1 + m * 128 + (((ct1 * 4 + gq) ^ msw) << 4) + 8 * lh) = o;
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + MID + 8 * gq);
+          u32x2 o;
+          o[0] = relu_pk(pack2(acc2[i][4 * gq] * sv[0] + bv[0], acc2[i][4 * gq + 1] * sv[1] + bv[1]), 0xffffffffu);
+          o[1] = relu_pk(pack2(acc2[i][4 * gq + 2] * sv[2] + bv[2], acc2[i][4 * gq + 3] * sv[3] + bv[3]), 0xffffffffu);
+          *reinterpret_cast<u32x2*>(wp + gq * 16) = o;
         }
       }
     }
@@ -319,17 +322,16 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     {
       int lz3;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz3));
-      const int l31c = l31 + lz3;
-      const int swz8 = (l31c >> 1) & 7;
+      const char* pbase = t1 + (l31 + lz3) * TP + 16 * lh;
+      const float* sp = s3 + 64 * wave + 4 * lh;  // b3 = s3 + 256
       bf16x8 av[2][4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) av[0][ks] = *reinterpret_cast<const bf16x8*>(t1 + l31c * 128 + (((ks * 2 + lh) ^ swz8) << 4));
+      for (int ks = 0; ks < 4; ++ks) av[0][ks] = *reinterpret_cast<const bf16x8*>(pbase + ks * 32);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         if (rt < 3) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            av[(rt + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(t1 + ((rt + 1) * 32 + l31c) * 128 + (((ks * 2 + lh) ^ swz8) << 4));
+          for (int ks = 0; ks < 4; ++ks) av[(rt + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(pbase + (rt + 1) * 32 * TP + ks * 32);
         }
         f32x16 acc3[2];
 #pragma unroll
@@ -343,25 +345,22 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            const int n0 = 64 * wave + 32 * j + 8 * gq + 4 * lh;
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(s3 + n0), bv = *reinterpret_cast<const f32x4*>(b3 + n0);
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 32 * j + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + C + 32 * j + 8 * gq);
             const u32x2 rv = res[rt * 8 + j * 4 + gq];
-            const float r4[4] = {__uint_as_float(rv[0] << 16), __uint_as_float(rv[0] & 0xffff0000u), __uint_as_float(rv[1] << 16),
-                                 __uint_as_float(rv[1] & 0xffff0000u)};
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            u32x2 o;
 #ifdef BK_NOE3
-              o[e] = (bf16_t)(acc3[j][4 * gq + e] + (e == 0 ? sv[0] + bv[0] + r4[0] : 0.f));
+            o[0] = pack2(acc3[j][4 * gq] + sv[0] + bv[0] + __uint_as_float(rv[0]), acc3[j][4 * gq + 1]);
+            o[1] = pack2(acc3[j][4 * gq + 2], acc3[j][4 * gq + 3] + __uint_as_float(rv[1]));
 #else
-              const float v = acc3[j][4 * gq + e] * sv[e] + bv[e] + r4[e];
-              o[e] = (bf16_t)(v > 0.f ? v : 0.f);
+            o[0] = relu_pk(pack2(acc3[j][4 * gq] * sv[0] + bv[0] + __uint_as_float(rv[0] << 16),
+                                 acc3[j][4 * gq + 1] * sv[1] + bv[1] + __uint_as_float(rv[0] & 0xffff0000u)), 0xffffffffu);
+            o[1] = relu_pk(pack2(acc3[j][4 * gq + 2] * sv[2] + bv[2] + __uint_as_float(rv[1] << 16),
+                                 acc3[j][4 * gq + 3] * sv[3] + bv[3] + __uint_as_float(rv[1] & 0xffff0000u)), 0xffffffffu);
 #endif
-            }
 #ifdef BK_NOSTORE
-            if (pv[rt] && o[0] == (bf16_t)1234.5f) *reinterpret_cast<bf16x4*>(y + ypos[rt] + n0) = o;
+            if (o[0] == 0x12345678u) *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
 #else
-            if (pv[rt]) *reinterpret_cast<bf16x4*>(y + ypos[rt] + n0) = o;
+            *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
 #endif
           }
       }

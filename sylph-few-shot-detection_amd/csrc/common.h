@@ -67,6 +67,7 @@ struct BottleneckArgs {
   const __bf16 *w1, *w2, *w3;
   const float *s1, *b1, *s2, *b2, *s3, *b3;
   const void* zeros;
+  void* trash;  // >= 256 CUs x 256 threads x 128 B: where lanes without a valid output position put their (fixed number of) stores
   const BkTile* bk;
   int n_tiles;
 };

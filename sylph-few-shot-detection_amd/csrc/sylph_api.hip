@@ -791,6 +791,7 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
     RET(c->dalloc(&Yb, (size_t)B * Hs * Ws * cout * e));
     auto& blocks = c->stages[si];
     void* Y = nullptr;
+    void* bk_trash = nullptr;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
       const auto& blk = blocks[bi];
       const int stride = bi == 0 ? first_stride : 1;
@@ -802,7 +803,8 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
       // 64-channel intermediates and the second read of x never reach HBM (2 048 -> 1 024 B per position)
       static const int fuse_bn = getenv("SYLPH_FUSE_BOTTLENECK") ? atoi(getenv("SYLPH_FUSE_BOTTLENECK")) : 1;
       if (fuse_bn && dt == DT_BF16 && !blk.has_sc && stride == 1 && mid == 64 && Cin == 256 && cout == 256 &&
-          blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3.Cout_pad == 256) {
+          blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3.Cout_pad == 256 &&
+          (size_t)B * Hin * Win * 512 < ((size_t)1 << 32)) {  // the kernel addresses x with 32-bit byte offsets
         BottleneckArgs ba;
         memset(&ba, 0, sizeof(ba));
         ba.x = X; ba.y = Y;
@@ -810,6 +812,8 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
         ba.s1 = blk.c1.scale; ba.b1 = blk.c1.shift; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
         ba.s3 = blk.c3.scale; ba.b3 = blk.c3.shift;
         ba.zeros = c->zeros;
+        if (!bk_trash) RET(c->dalloc(&bk_trash, (size_t)1024 * 256 * 128));  // per-thread trash slots (grid <= CU count <= 1024)
+        ba.trash = bk_trash;
         std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
         std::vector<BkTile> bt;
         int ph, pw;
