@@ -13,6 +13,7 @@ LAYERS = {
     "res2.conv1": (200, 336, 256, 64, 1, 1, 0, 0, 0),
     "res3.conv3": (100, 168, 128, 512, 1, 1, 0, 1, 0),
     "tower": (100, 168, 256, 256, 3, 1, 1, 0, 1),
+    "tower.gnin": (100, 168, 256, 256, 3, 1, 1, 0, 3),  # GroupNorm+ReLU of the previous layer applied to the halo in LDS
     "fpn.out3": (100, 168, 256, 256, 3, 1, 1, 0, 0),
     "res4.conv2": (50, 84, 256, 256, 3, 1, 1, 0, 0),
     "res3.conv2": (100, 168, 128, 128, 3, 1, 1, 0, 0),
@@ -21,5 +22,5 @@ name = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 H, W, ci, co, k, s, p, res, gn = LAYERS[name]
 eng = Engine(None, dtype="bf16")
-ms, tf = eng.bench_conv(B, H, W, ci, co, k, s, p, bool(res), True, bool(gn), iters=5)
+ms, tf = eng.bench_conv(B, H, W, ci, co, k, s, p, bool(res), True, int(gn), iters=5)
 print(name, ms * 1e3, "us", tf, "TF")

@@ -35,16 +35,17 @@ for L in layers:
         d["launches_seen"] = max(a[0] for a in cs.values())
         der = {}
         if d.get("SQ_BUSY_CYCLES") and d.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-            # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD summed over SIMDs (32 x N_mfma); SQ_BUSY_CYCLES per SE -> use GRBM when present
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 256 x 4 SIMDs (= 32 cycles x SQ_INSTS_MFMA for the 8-pass bf16 MFMA);
+            # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4) -> / 32 = the launch's duration in shader clocks
             der["mfma_busy_cycles_per_simd"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (256 * 4)
+            der["kernel_cycles"] = d["SQ_BUSY_CYCLES"] / 32
+            der["mfma_util"] = round(der["mfma_busy_cycles_per_simd"] / der["kernel_cycles"], 4)
         if d.get("SQ_WAVE_CYCLES"):
             for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
                 if c in d:
                     der[c + "/WAVE_CYCLES"] = round(d[c] / d["SQ_WAVE_CYCLES"], 4)
         if d.get("SQ_LDS_IDX_ACTIVE"):
             der["lds_bank_conflict_frac"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"], 4)
-        if d.get("GRBM_GUI_ACTIVE") and "mfma_busy_cycles_per_simd" in der:
-            der["mfma_util_vs_gpu_active"] = round(der["mfma_busy_cycles_per_simd"] / d["GRBM_GUI_ACTIVE"], 4)
         d["derived"] = der
         res[L][k] = d
 json.dump({"batch": B, "layers": res}, open(f"{out}/pmc_mfma.json", "w"), indent=1)

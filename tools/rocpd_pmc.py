@@ -3,8 +3,8 @@
 
     python tools/rocpd_pmc.py <fetch.db> <write.db> <batch> [out.json]
 
-Sums the counters over the conv_igemm_kernel launches of the LAST query step (from the last
-preprocess_kernel dispatch on).  Units/corrections as MI355X_MICROARCH.md prescribes: the counters are
+Sums the counters over the conv launches (conv_igemm_kernel, conv_hpipe_kernel, bottleneck64_kernel) of the LAST query
+step (from the last preprocess_kernel dispatch on); also reports the sum over EVERY kernel of that step.  Units/corrections as MI355X_MICROARCH.md prescribes: the counters are
 KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
 used as is (checked here against preprocess_kernel, whose write volume is known exactly)."""
 import json
@@ -18,13 +18,17 @@ def last_step(dbfile, counter):
                       (counter,)).fetchall()
     idx = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]][-1]
     step = rows[idx:]
-    conv = [r for r in step if "conv_igemm_kernel" in r[0] or "conv_pipe_kernel" in r[0]]
+    conv = [r for r in step if any(k in r[0] for k in ("conv_igemm_kernel", "conv_hpipe_kernel", "bottleneck64_kernel"))]
     pre = step[0][1]
-    return sum(r[1] for r in conv) * 1024.0, len(conv), pre * 1024.0
+    by = {}
+    for r in step:
+        k = r[0].split("(")[0].replace("sylph::", "").replace("void ", "")[:48]
+        by[k] = by.get(k, 0.0) + r[1] * 1024.0
+    return sum(r[1] for r in conv) * 1024.0, len(conv), pre * 1024.0, sum(r[1] for r in step) * 1024.0, by
 
 
-fetch, n1, pre_f = last_step(sys.argv[1], "FETCH_SIZE")
-write, n2, pre_w = last_step(sys.argv[2], "WRITE_SIZE")
+fetch, n1, pre_f, fetch_all, fetch_by = last_step(sys.argv[1], "FETCH_SIZE")
+write, n2, pre_w, write_all, write_by = last_step(sys.argv[2], "WRITE_SIZE")
 B = int(sys.argv[3])
 assert n1 == n2, (n1, n2)
 out = {
@@ -32,6 +36,8 @@ out = {
     "fetch_bytes_raw_per_step": fetch, "fetch_bytes_corrected_per_step": 2.0 * fetch, "write_bytes_per_step": write,
     "hbm_bytes_per_image": (2.0 * fetch + write) / B,
     "hbm_bytes_per_launch": (2.0 * fetch + write) / n1,
+    "all_kernels_hbm_bytes_per_image": (2.0 * fetch_all + write_all) / B,
+    "per_kernel_hbm_bytes_per_image": {k: round((2.0 * fetch_by.get(k, 0.0) + write_by.get(k, 0.0)) / B) for k in sorted(set(fetch_by) | set(write_by))},
     "calibration": {"preprocess_write_bytes": pre_w, "preprocess_write_expected": B * 800 * 1344 * 4 * 2,
                     "preprocess_fetch_bytes_raw": pre_f, "preprocess_fetch_expected": B * 3 * 800 * 1333 * 4},
     "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncorrected",
