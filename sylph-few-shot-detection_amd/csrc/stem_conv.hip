@@ -173,6 +173,207 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const bf16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem + 3x3 stride-2 max-pool in ONE kernel (BasicStem.forward: conv1 -> norm -> relu -> max_pool2d(3, 2, 1)).
+// Unfused, the 64-channel stem output (2.2 GB at B = 64, 800 x 1344) is written by stem_conv_kernel and read back by
+// maxpool_kernel: both launches run at the HBM rate (0.69 + 0.60 ms).  Here a tile is 17 x 15 stem positions (two MFMA passes
+// of 128; 14 % recompute at the overlapping row / column) = 8 x 7 pooled positions: the stem tile goes to LDS as bf16
+// (the same rounding the unfused path applies before pooling, so the result is bit-identical) and only the pooled
+// tensor (0.55 GB) is written.  Stem positions outside the image are stored as 0: every value is a ReLU output (>= 0) and each
+// window holds at least one real position, so 0 is as good as the -inf padding of max_pool2d.
+namespace {
+constexpr int FR = 17, FC = 15;                  // stem tile
+constexpr int FPR = 8, FPC = 7;                  // pooled tile
+constexpr int FPROWS = 2 * FR + 5, FPCOLS = 36;  // input patch: 39 rows x (2 * 15 + 5 = 35, + the zero-weight 8th column)
+constexpr int FPATCH_BYTES = 15104;              // 39 * 48 * 8 = 14 976, rounded to 128
+constexpr int FTP = 144;                         // stem tile row pitch: 64 ch bf16 + 16 B pad
+constexpr int FTILE_BYTES = FR * FC * FTP;       // 36 720
+constexpr int FNLOAD = (FPROWS * FPCOLS + 255) / 256;  // 6
+constexpr int FLDS = FPATCH_BYTES + ((FTILE_BYTES + 127) / 128) * 128 + 128 * 4;
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           bf16_t* __restrict__ out, char* __restrict__ trash, int H, int W, int H2,
+                                                           int W2, int H4, int W4, int tiles_y, int tiles_x, int ntiles) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* st = smem + FPATCH_BYTES;
+  float* ss = reinterpret_cast<float*>(smem + FPATCH_BYTES + ((FTILE_BYTES + 127) / 128) * 128);  // scale[64], shift[64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+
+  bf16x8 wb[14][2];
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wb[ks][j] = *reinterpret_cast<const bf16x8*>(wp + (j * 32 + l31) * 224 + ks * 16 + lh * 8);
+  if (tid < 128) ss[tid] = tid < 64 ? scale[tid] : shift[tid - 64];
+
+  // per pass p: this lane's stem position m = p * 128 + wave * 32 + l31 (m = 255 does not exist: it recomputes 254 and is dropped)
+  int aoff[2], sy[2], sx[2], toff[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int m = min(p * 128 + wave * 32 + l31, FR * FC - 1);
+    sy[p] = m / FC;
+    sx[p] = m - sy[p] * FC;
+    aoff[p] = ((2 * sy[p]) * PP + 2 * sx[p] + 2 * lh) * 8;
+    toff[p] = (p * 128 + wave * 32 + l31 < FR * FC) ? m * FTP + 8 * lh : -1;
+  }
+  int f_pr[FNLOAD], f_pc[FNLOAD], f_lds[FNLOAD];
+  uint32_t f_in = 0;
+#pragma unroll
+  for (int r = 0; r < FNLOAD; ++r) {
+    const int idx = tid + 256 * r;
+    f_pr[r] = idx / FPCOLS; f_pc[r] = idx - f_pr[r] * FPCOLS;
+    f_lds[r] = (f_pr[r] * PP + f_pc[r]) * 8;
+    f_in |= (idx < FPROWS * FPCOLS ? 1u : 0u) << r;
+  }
+  // pooled outputs of this lane: item tid + 256 r -> (pooled position, 8-channel group)
+  int p_off[2], p_oy[2], p_ox[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int idx = tid + 256 * r, pp = idx >> 3;
+    p_oy[r] = pp / FPC; p_ox[r] = pp - p_oy[r] * FPC;
+    p_off[r] = pp < FPR * FPC ? ((2 * p_oy[r]) * FC + 2 * p_ox[r]) * FTP + (idx & 7) * 16 : -1;
+  }
+  char* const my_trash = trash + ((size_t)blockIdx.x * 256 + tid) * 16;
+
+  auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y;
+    b = t2 / tiles_y; oy0 = ty * FPR; ox0 = tx * FPC;
+  };
+  auto fetch = [&](int tile_in, uint2 (&v)[FNLOAD], uint32_t& okmask) {
+    int b, oy0, ox0;
+    tile_origin(tile_in < ntiles ? tile_in : ntiles - 1, b, oy0, ox0);
+    const int iy0 = 4 * oy0 - 5, ix0 = 4 * ox0 - 5;  // stem row 2 oy0 - 1 reads input rows 2 (2 oy0 - 1) - 3 ..
+    okmask = 0;
+    const bf16_t* xb = x + (size_t)b * H * W * 4;
+#pragma unroll
+    for (int r = 0; r < FNLOAD; ++r) {
+      const int iy = iy0 + f_pr[r], ix = ix0 + f_pc[r];
+      const bool ok = ((f_in >> r) & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+      const bf16_t* src = xb + (cy * W + cx) * 4;
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v[r]) : "v"(src) : "memory");
+      okmask |= (ok ? 1u : 0u) << r;
+    }
+  };
+  auto park = [&](const uint2 (&v)[FNLOAD], uint32_t okmask) {
+#pragma unroll
+    for (int r = 0; r < FNLOAD; ++r) {
+      const uint2 t = ((okmask >> r) & 1u) ? v[r] : make_uint2(0u, 0u);
+      if ((f_in >> r) & 1u) *reinterpret_cast<uint2*>(patch + f_lds[r]) = t;
+    }
+  };
+#pragma unroll
+  for (int ks = 0; ks < 14; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(wb[ks][j]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int g = gridDim.x;
+  int nth = 0;
+  auto do_tile = [&](int tile, uint2 (&q)[FNLOAD], uint32_t& qm) {
+    // issued after this tile's patch loads (two tiles ago): 2 stores, the next tile's 6 loads, 2 stores -- all may stay in flight
+    // (the first two tiles have fewer operations behind their patch)
+    static_assert(FNLOAD == 6, "the vmcnt immediates below are FNLOAD (+ 2 stores per finished tile)");
+    if (nth == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (nth == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    ++nth;
+    park(q, qm);
+    lds_barrier();
+    fetch(tile + 2 * g, q, qm);
+    int b, oy0, ox0;
+    tile_origin(tile, b, oy0, ox0);
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(patch + aoff[p] + (kh * PP + 4 * h) * 8);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kh * 2 + h][j], fa, acc[j], 0, 0, 0);
+        }
+      // D^T layout: this lane holds channels 32 j + 8 q4 + 4 lh .. + 3 of its position
+      const bool inimg = (unsigned)(sy0 + sy[p]) < (unsigned)H2 && (unsigned)(sx0 + sx[p]) < (unsigned)W2;
+      const unsigned keep = inimg ? 0xffffffffu : 0u;
+      if (toff[p] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int n0 = 32 * j + 8 * q4 + 4 * lh;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(ss + n0), bv = *reinterpret_cast<const f32x4*>(ss + 64 + n0);
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            u32x2 o;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              bf16x2 v2;
+              v2[0] = (bf16_t)(acc[j][4 * q4 + 2 * hh] * sv[2 * hh] + bv[2 * hh]);
+              v2[1] = (bf16_t)(acc[j][4 * q4 + 2 * hh + 1] * sv[2 * hh + 1] + bv[2 * hh + 1]);
+              const s16x2 z = {0, 0};
+              o[hh] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v2), z)) & keep;  // ReLU on the bf16 pair
+            }
+            *reinterpret_cast<u32x2*>(st + toff[p] + 64 * j + 16 * q4) = o;
+          }
+      }
+    }
+    lds_barrier();
+    // pool: 9 taps of 16 B; non-negative bf16 order like their bit patterns, so the max is a packed unsigned 16-bit max
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+      u16x8 mx = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (p_off[r] >= 0) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            mx = __builtin_elementwise_max(mx, *reinterpret_cast<const u16x8*>(st + p_off[r] + (dy * FC + dx) * FTP));
+      }
+      const int oy = oy0 + p_oy[r], ox = ox0 + p_ox[r];
+      const bool okp = p_off[r] >= 0 && oy < H4 && ox < W4;
+      char* dst = okp ? reinterpret_cast<char*>(out) + ((((size_t)b * H4 + oy) * W4 + ox) * 64 + (tid & 7) * 8) * 2 : my_trash;
+      *reinterpret_cast<u16x8*>(dst) = mx;  // unconditional: a fixed number of stores per tile keeps the vmcnt arithmetic exact
+    }
+    lds_barrier();  // patch and stem tile are rewritten by the next tile
+  };
+
+  uint2 qa[FNLOAD], qb[FNLOAD];
+  uint32_t ma, mb;
+  int tile = blockIdx.x;
+  fetch(tile, qa, ma);
+  fetch(tile + g, qb, mb);
+  while (tile < ntiles) {
+    do_tile(tile, qa, ma);
+    tile += g;
+    if (tile >= ntiles) break;
+    do_tile(tile, qb, mb);
+    tile += g;
+  }
+}
+
+// out: [B][H4][W4][64] (the max-pooled stem); trash: >= grid x 256 x 16 B
+int launch_stem_pool(const void* x, const void* wp, const float* scale, const float* shift, void* out, void* trash, int B, int H, int W,
+                     int H2, int W2, int H4, int W4, hipStream_t s) {
+  const int tiles_y = (H4 + FPR - 1) / FPR, tiles_x = (W4 + FPC - 1) / FPC, ntiles = B * tiles_y * tiles_x;
+  const int grid = ntiles < 512 ? ntiles : 512;  // 2 persistent blocks per CU
+  hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), FLDS, s, (const bf16_t*)x, (const bf16_t*)wp, scale, shift, (bf16_t*)out,
+                     (char*)trash, H, W, H2, W2, H4, W4, tiles_y, tiles_x, ntiles);
+  return (int)hipGetLastError();
+}
+
 // wp: [64][7][8][4] bf16 (kernel column 7 and channel 3 zero); x: [B][H][W][4]; out: [B][H2][W2][64]
 int launch_stem_conv(const void* x, const void* wp, const float* scale, const float* shift, void* out, int B, int H, int W, int H2,
                      int W2, hipStream_t s) {

@@ -766,13 +766,24 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
       const void *x0 = P->x0, *wp = c->stem_wp;
       const float *scl = c->stem.scale, *shf = c->stem.shift;
       const double fl = os.flops;
-      ops.push_back([=](hipStream_t s) {
-        return timed_op(c, fl, s, [=](hipStream_t st) { return launch_stem_conv(x0, wp, scl, shf, so, B, H, W, H2, W2, st); });
-      });
+      // stem + max-pool in one kernel: the 64-channel stem output never reaches HBM (stem_conv.hip)
+      static const int fuse_pool = getenv("SYLPH_FUSE_STEM_POOL") ? atoi(getenv("SYLPH_FUSE_STEM_POOL")) : 1;
+      if (fuse_pool) {
+        void* trash = nullptr;
+        RET(c->dalloc(&trash, (size_t)512 * 256 * 16));
+        ops.push_back([=](hipStream_t s) {
+          return timed_op(c, fl, s, [=](hipStream_t st) { return launch_stem_pool(x0, wp, scl, shf, po, trash, B, H, W, H2, W2, H4, W4, st); });
+        });
+      } else {
+        ops.push_back([=](hipStream_t s) {
+          return timed_op(c, fl, s, [=](hipStream_t st) { return launch_stem_conv(x0, wp, scl, shf, so, B, H, W, H2, W2, st); });
+        });
+        ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
+      }
     } else {
       RET(add_conv(c, ops, c->stem, P->x0, 4, so, 64, image_segs(B, H, W, H2, W2), os));
+      ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
     }
-    ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
   }
   const void* X = P->pool_out;
   int Hin = H4, Win = W4, Cin = 64;
@@ -2024,7 +2035,14 @@ int sylph_stem_maxpool(sylph_ctx* c, const float* x, int B, int H, int W, const 
   const float mean0[3] = {0.f, 0.f, 0.f}, std1[3] = {1.f, 1.f, 1.f};
   KCHK(launch_preprocess(c->dt, idd, x0, B, H, W, mean0, std1, c->stream), "preprocess");
   KCHK(launch_stem_conv(x0, wpd, scd, shd, so, B, H, W, H2, W2, c->stream), "stem_conv");
-  KCHK(launch_maxpool(c->dt, so, po, B, H2, W2, 64, H4, W4, c->stream), "maxpool");
+  static const int fuse_pool = getenv("SYLPH_FUSE_STEM_POOL") ? atoi(getenv("SYLPH_FUSE_STEM_POOL")) : 1;
+  if (fuse_pool) {  // the product path: pool_out comes from the fused kernel, stem_out from the stand-alone stem kernel
+    void* trash;
+    RET(tmp.dalloc(&trash, (size_t)512 * 256 * 16));
+    KCHK(launch_stem_pool(x0, wpd, scd, shd, po, trash, B, H, W, H2, W2, H4, W4, c->stream), "stem_pool");
+  } else {
+    KCHK(launch_maxpool(c->dt, so, po, B, H2, W2, 64, H4, W4, c->stream), "maxpool");
+  }
   for (int b = 0; b < B; ++b) {
     if (stem_out) KCHK(launch_export_nchw(c->dt, so, stem_out + (size_t)b * 64 * H2 * W2, 64, H2 * W2, b * H2 * W2, 64, c->stream), "export");
     if (pool_out) KCHK(launch_export_nchw(c->dt, po, pool_out + (size_t)b * 64 * H4 * W4, 64, H4 * W4, b * H4 * W4, 64, c->stream), "export");
