@@ -52,6 +52,9 @@ constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 #define BK_MFMA_DRAIN2(a0, a1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1)::"memory")
 #define BK_MFMA_DRAIN3(a0, a1, a2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2)::"memory")
 
+#ifndef BK_ONLY
+#define BK_ONLY 0  // ablation builds: run only phase 1, 2 or 3 of every tile (4: none)
+#endif
 #ifdef BK_NOBAR
 #define BK_BAR() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
@@ -103,6 +106,15 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     bn[i] = *src;
   }
   const float *s1 = bn, *b1 = bn + MID, *s2 = bn + 2 * MID, *b2 = bn + 3 * MID, *s3 = bn + 4 * MID, *b3 = bn + 4 * MID + C;
+  // conv3's FrozenBN constants of this lane's 64 output channels stay in registers (P3 is VALU bound: 64 fewer LDS reads per tile)
+  f32x4 s3r[2][4], b3r[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      s3r[j][gq] = *reinterpret_cast<const f32x4*>(a.s3 + 64 * wave + 32 * j + 8 * gq + 4 * lh);
+      b3r[j][gq] = *reinterpret_cast<const f32x4*>(a.b3 + 64 * wave + 32 * j + 8 * gq + 4 * lh);
+    }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // persistent tile walk: blocks of one XCD (blockIdx & 7) take neighbouring patches at the same time
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     // ===== P1: t1 = relu(bn1(x_halo . W1^T)), row tiles rb1 .. rb1+2, channels ct1 ===========================================
     // (lz*: zero, opaque to the compiler and re-made per tile and phase: LDS addresses would otherwise be hoisted out of the tile
     //  loop as ~150 loop-invariant VGPRs, leaving no registers to pipeline the fragment reads)
-    {
+    if (BK_ONLY == 0 || BK_ONLY == 1) {
       int lz1;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz1));
       const int l31a = l31 + lz1;
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     // ===== P2: t2 = relu(bn2(conv3x3(t1))), row tiles rb2, rb2+1, channels ct1 ===============================================
     // t1 / t2 rows are PADDED to 144 B (they are written by ds_write, not by DMA): conflict-free without a swizzle, so the
     // k-step and tile offsets of every read are instruction immediates (one VALU add per tap and tile instead of per read)
-    {
+    if (BK_ONLY == 0 || BK_ONLY == 2) {
       int lz2;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz2));
       const int l31b = l31 + lz2;
@@ -319,50 +331,60 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     BK_BAR();  // t2 complete
 
     // ===== P3: y = relu(bn3(t2 . W3^T) + x), all four row tiles, channels 64 wave .. 64 wave + 63 ==========================
-    {
+    // Software pipelined over the row tiles: the 8 MFMAs of tile rt + 1 are issued one per epilogue chunk of tile rt (k-step
+    // outer, channel tile inner, so the two dependent chains alternate).  Back to back they would stall the wave's in-order
+    // issue for ~8 x 40 cycles per tile and then leave the matrix pipe idle during ~600 cycles of epilogue VALU work.
+    if (BK_ONLY == 0 || BK_ONLY == 3) {
       int lz3;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz3));
       const char* pbase = t1 + (l31 + lz3) * TP + 16 * lh;
-      const float* sp = s3 + 64 * wave + 4 * lh;  // b3 = s3 + 256
       bf16x8 av[2][4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) av[0][ks] = *reinterpret_cast<const bf16x8*>(pbase + ks * 32);
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        if (rt < 3) {
+        for (int ks = 0; ks < 4; ++ks) av[b][ks] = *reinterpret_cast<const bf16x8*>(pbase + b * 32 * TP + ks * 32);
+      f32x16 acc3[2][2];  // [buffer][channel tile]
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) av[(rt + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(pbase + (rt + 1) * 32 * TP + ks * 32);
-        }
-        f32x16 acc3[2];
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          BK_MFMA0(acc3[j], W3f[j][0], av[rt & 1][0]);
-#pragma unroll
-          for (int ks = 1; ks < 4; ++ks) BK_MFMA(acc3[j], W3f[j][ks], av[rt & 1][ks]);
+          if (ks == 0) BK_MFMA0(acc3[0][j], W3f[j][0], av[0][0]);
+          else BK_MFMA(acc3[0][j], W3f[j][ks], av[0][ks]);
         }
-        BK_MFMA_DRAIN2(acc3[0], acc3[1]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int rt = 0; rt < 4; ++rt) {
+        const int cb = rt & 1, nb = cb ^ 1;
+        BK_MFMA_DRAIN2(acc3[cb][0], acc3[cb][1]);
+        if (rt + 2 < 4) {  // fragments of tile rt + 2 into the buffer tile rt has just finished with
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 32 * j + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + C + 32 * j + 8 * gq);
-            const u32x2 rv = res[rt * 8 + j * 4 + gq];
-            u32x2 o;
+          for (int ks = 0; ks < 4; ++ks) av[cb][ks] = *reinterpret_cast<const bf16x8*>(pbase + (rt + 2) * 32 * TP + ks * 32);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int j = c >> 2, gq = c & 3;
+          if (rt < 3) {
+            const int ks2 = c >> 1, j2 = c & 1;
+            if (ks2 == 0) BK_MFMA0(acc3[nb][j2], W3f[j2][0], av[nb][0]);
+            else BK_MFMA(acc3[nb][j2], W3f[j2][ks2], av[nb][ks2]);
+          }
+          const f32x4 sv = s3r[j][gq], bv = b3r[j][gq];
+          const u32x2 rv = res[rt * 8 + j * 4 + gq];
+          u32x2 o;
 #ifdef BK_NOE3
-            o[0] = pack2(acc3[j][4 * gq] + sv[0] + bv[0] + __uint_as_float(rv[0]), acc3[j][4 * gq + 1]);
-            o[1] = pack2(acc3[j][4 * gq + 2], acc3[j][4 * gq + 3] + __uint_as_float(rv[1]));
+          o[0] = pack2(acc3[cb][j][4 * gq] + sv[0] + bv[0] + __uint_as_float(rv[0]), acc3[cb][j][4 * gq + 1]);
+          o[1] = pack2(acc3[cb][j][4 * gq + 2], acc3[cb][j][4 * gq + 3] + __uint_as_float(rv[1]));
 #else
-            o[0] = relu_pk(pack2(acc3[j][4 * gq] * sv[0] + bv[0] + __uint_as_float(rv[0] << 16),
-                                 acc3[j][4 * gq + 1] * sv[1] + bv[1] + __uint_as_float(rv[0] & 0xffff0000u)), 0xffffffffu);
-            o[1] = relu_pk(pack2(acc3[j][4 * gq + 2] * sv[2] + bv[2] + __uint_as_float(rv[1] << 16),
-                                 acc3[j][4 * gq + 3] * sv[3] + bv[3] + __uint_as_float(rv[1] & 0xffff0000u)), 0xffffffffu);
+          o[0] = relu_pk(pack2(acc3[cb][j][4 * gq] * sv[0] + bv[0] + __uint_as_float(rv[0] << 16),
+                               acc3[cb][j][4 * gq + 1] * sv[1] + bv[1] + __uint_as_float(rv[0] & 0xffff0000u)), 0xffffffffu);
+          o[1] = relu_pk(pack2(acc3[cb][j][4 * gq + 2] * sv[2] + bv[2] + __uint_as_float(rv[1] << 16),
+                               acc3[cb][j][4 * gq + 3] * sv[3] + bv[3] + __uint_as_float(rv[1] & 0xffff0000u)), 0xffffffffu);
 #endif
 #ifdef BK_NOSTORE
-            if (o[0] == 0x12345678u) *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
+          if (o[0] == 0x12345678u) *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
 #else
-            *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
+          *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
 #endif
-          }
+        }
       }
     }
     t = t_next;
