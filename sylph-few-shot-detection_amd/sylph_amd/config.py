@@ -2,7 +2,7 @@
 reads, ``_BASE_`` inheritance and the ``sylph://`` prefix.
 
 Mirrors (reference paths relative to /root/reference):
-  * sylph/config/config.py:20-65        CfgNode.merge_from_file, ``sylph://`` -> <package>/configs/,
+  * sylph/config/config.py:20-65        CfgNode.merge_from_file, ``sylph://`` -> $SYLPH_CONFIG_ROOT, else sylph_amd.recipes,
                                         ``_BASE_`` rerouting
   * sylph/runner/adet_configs.py:25-61  MODEL.FCOS.* defaults
   * sylph/runner/default_configs.py:8-167  DATASETS.*, MODEL.BACKBONE.FREEZE*, MODEL.PROPOSAL_GENERATOR.*,
@@ -24,22 +24,21 @@ SYLPH_PREFIX = "sylph://"
 
 
 def config_roots() -> List[str]:
-    """Directories searched for ``sylph://<rel>``: $SYLPH_CONFIG_ROOT (':'-separated), then the
-    package's own ``configs/``."""
-    roots = [r for r in os.environ.get("SYLPH_CONFIG_ROOT", "").split(":") if r]
-    roots.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs"))
-    return roots
+    """Directories searched for ``sylph://<rel>``: $SYLPH_CONFIG_ROOT (':'-separated; e.g. the reference's own
+    ``configs/`` directory, whose yamls load unchanged).  Names found in no root fall back to the built-in inference
+    recipes of sylph_amd.recipes."""
+    return [r for r in os.environ.get("SYLPH_CONFIG_ROOT", "").split(":") if r]
 
 
 def reroute_config_path(path: str) -> str:
-    """sylph/config/config.py:32-42."""
+    """sylph/config/config.py:32-42.  A ``sylph://`` name that exists under no config root is returned unchanged
+    (load_yaml_with_base then looks it up among the built-in recipes)."""
     if path.startswith(SYLPH_PREFIX):
         rel = path[len(SYLPH_PREFIX):]
         for root in config_roots():
             cand = os.path.join(root, rel)
             if os.path.exists(cand):
                 return cand
-        return os.path.join(config_roots()[-1], rel)
     return path
 
 
@@ -92,6 +91,12 @@ class CfgNode(dict):
     @staticmethod
     def load_yaml_with_base(filename: str) -> dict:
         filename = reroute_config_path(filename)
+        if filename.startswith(SYLPH_PREFIX):
+            from .recipes import get_recipe
+            recipe = get_recipe(filename[len(SYLPH_PREFIX):])
+            if recipe is None:
+                raise FileNotFoundError(f"{filename}: not under $SYLPH_CONFIG_ROOT and not a built-in recipe")
+            return recipe
         with open(filename, "r") as f:
             cfg = yaml.safe_load(f) or {}
         if BASE_KEY in cfg:
