@@ -53,3 +53,10 @@ def test_parity_suite_with_halo_mode_forced():
     (SYLPH_CONV_HPIPE=0 keeps the 256-wide layers on it too): conv2d vs torch, head / decode / codegen goldens,
     backbone and episode vs the oracle all run through it."""
     _rerun({"SYLPH_CONV_HALO": "2", "SYLPH_CONV_HPIPE": "0"})
+
+
+def test_parity_suite_with_fusions_off():
+    """The unfused graph (res2 identity blocks as three launches, stem and max-pool as two, stand-alone GroupNorm applies)
+    must pass the same backbone / head / episode checks as the default fused one."""
+    _rerun({"SYLPH_FUSE_BOTTLENECK": "0", "SYLPH_FUSE_STEM_POOL": "0", "SYLPH_GN_FUSE": "0"},
+           "stem or backbone or head or episode or c3 or full_size_prop")

@@ -554,7 +554,7 @@ def test_full_size_f32_matches_oracle(full_sd):
           scores within 1e-3 and boxes within the stride-relative bound."""
     from oracle import backbone as OB, decode as OD, head as OH
     from sylph_amd import synthetic as W
-    if any(k.startswith("SYLPH_CONV") for k in os.environ):
+    if any(k.startswith(("SYLPH_CONV", "SYLPH_FUSE", "SYLPH_GN_FUSE")) for k in os.environ):
         pytest.skip("this test is about the DEFAULT kernel selection (forced-variant reruns set SYLPH_CONV_*)")
     eng = _engine("f32", _cfg())
     eng.load_state_dict(full_sd)
