@@ -392,6 +392,280 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// First block of res2 (64 -> 64 -> 64 -> 256, projection shortcut), same design.  What differs from the identity block:
+//   * x has 64 channels: a halo is 192 rows x 128 B = 24 KiB, so TWO halo buffers fit and the next patch's halo is issued at
+//     the top of a tile, a whole tile ahead (the identity block can only issue it after conv1);
+//   * no residual registers: conv3 and the projection are ONE GEMM over K = [t2 | x] (128) against the packed c3sc weights
+//     ([256][128], both FrozenBN scales folded in fp32 before the bf16 rounding, shifts summed -- sylph_api.hip), the x half of
+//     the A operand is read straight from the halo's centre rows;  y = relu(acc + shift).
+namespace {
+constexpr int PX_BYTES = XROWS * 128;         // one halo buffer
+constexpr int PT1_OFF = 2 * PX_BYTES;         // t1 / t2, pitch TP
+constexpr int PBN_OFF = PT1_OFF + XROWS * TP; // s1 b1 s2 b2
+constexpr int PLDS_BYTES = PBN_OFF + 4 * MID * 4;
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckArgs a) {
+  typedef bf16_t T;
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  T* __restrict__ y = reinterpret_cast<T*>(a.y);
+  char* const trash = reinterpret_cast<char*>(a.trash) + ((size_t)blockIdx.x * 256 + tid) * 128;
+  char* const t1 = smem + PT1_OFF;
+  float* const bn = reinterpret_cast<float*>(smem + PBN_OFF);
+
+  const int ct1 = wave >> 1;
+  bf16x8 W1f[4], W2f[36], W3f[2][8];
+  {
+    const T* w1p = a.w1 + ((ct1 * 32 + l31) * MID + lh * 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) W1f[ks] = *reinterpret_cast<const bf16x8*>(w1p + ks * 16);
+    const T* w2p = a.w2 + ((ct1 * 32 + l31) * 9 * MID + lh * 8);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) W2f[k] = *reinterpret_cast<const bf16x8*>(w2p + k * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const T* w3p = a.w3 + (((2 * wave + j) * 32 + l31) * (2 * MID) + lh * 8);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) W3f[j][ks] = *reinterpret_cast<const bf16x8*>(w3p + ks * 16);
+    }
+  }
+  for (int i = tid; i < 4 * MID; i += 256) {
+    const float* src = i < MID ? a.s1 + i : i < 2 * MID ? a.b1 + (i - MID) : i < 3 * MID ? a.s2 + (i - 2 * MID) : a.b2 + (i - 3 * MID);
+    bn[i] = *src;
+  }
+  const float *s1 = bn, *s2 = bn + 2 * MID;
+  f32x4 b3r[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) b3r[j][gq] = *reinterpret_cast<const f32x4*>(a.b3 + 64 * wave + 32 * j + 8 * gq + 4 * lh);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int G = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, gx = (G + 7) >> 3;
+  const int chunk = (a.n_tiles + 7) >> 3;
+  auto tile_of = [&](int it) { const int q = it * gx + jb; return __builtin_amdgcn_readfirstlane(q < chunk ? xcd * chunk + q : a.n_tiles); };
+  auto load_tile = [&](int t) {
+    i32x8 v;
+    const BkTile* p = a.bk + t;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+  };
+  // x halo -> LDS buffer `buf`: 6 rounds of 32 rows x 128 B; slot s of row r holds 16-byte chunk s ^ ((r >> 1) & 7); rows outside
+  // the image come from a clamped address (never used: P1 masks t1 there, P3 only stores valid positions)
+  const int xr = tid >> 3, xs = tid & 7;
+  auto issue_x = [&](const i32x8 d, int buf) {
+    const int row0 = d[0], H = d[1], W = d[2], oy0 = d[3] >> 16, ox0 = d[3] & 0xffff, HW2 = d[5] + 2, HR = (d[4] + 2) * HW2;
+    const unsigned inv_hw2 = (unsigned)d[7];
+    const int nr = (HR + 31) >> 5;
+    for (int r = 0; r < nr; ++r) {
+      const int h = r * 32 + xr;
+      const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
+      const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
+      const unsigned off = ((unsigned)(row0 + iy * W + ix) << 7) + (unsigned)((xs ^ ((h >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(smem + buf * PX_BYTES + r * 4096 + wave * 1024), 16, 0, 0);
+    }
+  };
+  auto relu_pk = [](unsigned u, unsigned keep) {
+    const s16x2 z = {0, 0};
+    const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), z);
+    return __builtin_bit_cast(unsigned, r) & keep;
+  };
+  auto pack2 = [](float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (bf16_t)lo;
+    v[1] = (bf16_t)hi;
+    return __builtin_bit_cast(unsigned, v);
+  };
+
+  int t = tile_of(0);
+  i32x8 td = load_tile(t < a.n_tiles ? t : 0);
+  if (t < a.n_tiles) issue_x(td, 0);
+  const int rb1 = (wave & 1) * 3, rb2 = (wave & 1) * 2;
+
+  for (int it = 0; t < a.n_tiles; ++it) {
+    const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
+    const int PW = td[5], HW2 = PW + 2, HR = (td[4] + 2) * HW2, NPOS = td[4] * PW;
+    const unsigned inv_pw = (unsigned)td[6], inv_hw2 = (unsigned)td[7];
+    const int t_next = tile_of(it + 1);
+    const i32x8 td_next = load_tile(t_next < a.n_tiles ? t_next : 0);
+    char* const xb = smem + (it & 1) * PX_BYTES;
+
+    // this tile's halo (issued a whole tile ago, before the previous tile's 32 stores) has landed
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    BK_BAR();  // ... for every wave; the other halo buffer and t1 / t2 of the previous tile are free
+    if (t_next < a.n_tiles) issue_x(td_next, (it & 1) ^ 1);
+
+    // ===== P1: t1 = relu(bn1(x_halo . W1^T)) =================================================================================
+    {
+      int lz1;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lz1));
+      const int l31a = l31 + lz1;
+      f32x16 acc1[3];
+      const char* abase = xb + (rb1 * 32 + l31a) * 128;
+      const int akey = ((((l31a >> 1) & 7)) ^ lh) << 4;
+      bf16x8 af[4][3];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const char* ap = abase + ((ks * 32) ^ akey);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(ap + i * 4096);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (ks == 0) BK_MFMA0(acc1[i], W1f[ks], af[ks][i]);
+          else BK_MFMA(acc1[i], W1f[ks], af[ks][i]);
+        }
+      BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
+      const float* sp = s1 + ct1 * 32 + 4 * lh;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int h = (rb1 + i) * 32 + l31a;
+        const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
+        const bool in1 = h < HR && (unsigned)(oy0 - 1 + hy) < (unsigned)IH && (unsigned)(ox0 - 1 + hx) < (unsigned)IW;
+        const unsigned keep = in1 ? 0xffffffffu : 0u;
+        char* wp = t1 + h * TP + ct1 * 64 + 8 * lh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + MID + 8 * gq);
+          u32x2 o;
+          o[0] = relu_pk(pack2(acc1[i][4 * gq] * sv[0] + bv[0], acc1[i][4 * gq + 1] * sv[1] + bv[1]), keep);
+          o[1] = relu_pk(pack2(acc1[i][4 * gq + 2] * sv[2] + bv[2], acc1[i][4 * gq + 3] * sv[3] + bv[3]), keep);
+          *reinterpret_cast<u32x2*>(wp + gq * 16) = o;
+        }
+      }
+    }
+    // output pointers and the halo-centre rows (the x half of conv3's A operand) of this lane's four positions
+    char* yptr[4];
+    int xoff[4];
+    int lzr;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lzr));
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int m = rt * 32 + l31 + lzr;
+      const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
+      const bool pv = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
+      yptr[rt] = pv ? reinterpret_cast<char*>(y) + ((size_t)(unsigned)(row0 + (oy0 + my) * IW + ox0 + mx) * (C * 2) + 128 * wave + 8 * lh) : trash;
+      const int hc = min((my + 1) * HW2 + mx + 1, XROWS - 1);
+      xoff[rt] = hc * 128 + (((((hc >> 1) & 7)) ^ lh) << 4);  // chunk pair ks' of this row sits at xoff ^ (ks' * 32)
+    }
+    BK_BAR();  // t1 complete
+
+    // ===== P2: t2 = relu(bn2(conv3x3(t1))) ==================================================================================
+    {
+      int lz2;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lz2));
+      const int l31b = l31 + lz2;
+      f32x16 acc2[2];
+      const char* hrow[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = (rb2 + i) * 32 + l31b;
+        const int my = (int)(((unsigned)m * inv_pw) >> 16);
+        hrow[i] = t1 + (my * HW2 + (m - my * PW)) * TP + 16 * lh;
+      }
+      auto p2_ptr = [&](int k, int i) {
+        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
+        return reinterpret_cast<const bf16x8*>(hrow[i] + (kh * HW2 + kw) * TP + ks * 32);
+      };
+      constexpr int D2 = 4;
+      bf16x8 af[D2][2];
+#pragma unroll
+      for (int k = 0; k < D2 - 1; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[k][i] = *p2_ptr(k, i);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D2 - 1), 0);
+#pragma unroll
+      for (int k = 0; k < 36; ++k) {
+        if (k + D2 - 1 < 36) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[(k + D2 - 1) % D2][i] = *p2_ptr(k + D2 - 1, i);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
+          else BK_MFMA(acc2[i], W2f[k], af[k % D2][i]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      }
+      BK_MFMA_DRAIN2(acc2[0], acc2[1]);
+      BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
+      const float* sp = s2 + ct1 * 32 + 4 * lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        char* wp = t1 + ((rb2 + i) * 32 + l31b) * TP + ct1 * 64 + 8 * lh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + MID + 8 * gq);
+          u32x2 o;
+          o[0] = relu_pk(pack2(acc2[i][4 * gq] * sv[0] + bv[0], acc2[i][4 * gq + 1] * sv[1] + bv[1]), 0xffffffffu);
+          o[1] = relu_pk(pack2(acc2[i][4 * gq + 2] * sv[2] + bv[2], acc2[i][4 * gq + 3] * sv[3] + bv[3]), 0xffffffffu);
+          *reinterpret_cast<u32x2*>(wp + gq * 16) = o;
+        }
+      }
+    }
+    BK_BAR();  // t2 complete
+
+    // ===== P3: y = relu([t2 | x] . [W3 | Wsc]^T + shift), software pipelined over the row tiles like the identity block ======
+    {
+      int lz3;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(lz3));
+      const char* pbase = t1 + (l31 + lz3) * TP + 16 * lh;
+      const char* xc = xb + lz3;
+      bf16x8 av[2][8];
+      auto load_av = [&](int b, int rt) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) av[b][ks] = *reinterpret_cast<const bf16x8*>(pbase + rt * 32 * TP + ks * 32);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) av[b][4 + ks] = *reinterpret_cast<const bf16x8*>(xc + (xoff[rt] ^ (ks * 32)));
+      };
+      load_av(0, 0);
+      load_av(1, 1);
+      f32x16 acc3[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (ks == 0) BK_MFMA0(acc3[0][j], W3f[j][0], av[0][0]);
+          else BK_MFMA(acc3[0][j], W3f[j][ks], av[0][ks]);
+        }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int cb = rt & 1, nb = cb ^ 1;
+        BK_MFMA_DRAIN2(acc3[cb][0], acc3[cb][1]);
+        if (rt + 2 < 4) load_av(cb, rt + 2);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int j = c >> 2, gq = c & 3;
+          if (rt < 3) {  // two of tile rt + 1's sixteen MFMAs per epilogue chunk: k-step c, both channel tiles
+            if (c == 0) { BK_MFMA0(acc3[nb][0], W3f[0][0], av[nb][0]); BK_MFMA0(acc3[nb][1], W3f[1][0], av[nb][0]); }
+            else { BK_MFMA(acc3[nb][0], W3f[0][c], av[nb][c]); BK_MFMA(acc3[nb][1], W3f[1][c], av[nb][c]); }
+          }
+          const f32x4 bv = b3r[j][gq];
+          u32x2 o;
+          o[0] = relu_pk(pack2(acc3[cb][j][4 * gq] + bv[0], acc3[cb][j][4 * gq + 1] + bv[1]), 0xffffffffu);
+          o[1] = relu_pk(pack2(acc3[cb][j][4 * gq + 2] + bv[2], acc3[cb][j][4 * gq + 3] + bv[3]), 0xffffffffu);
+          *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
+        }
+      }
+    }
+    t = t_next;
+    td = td_next;
+  }
+}
+
 int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s) {
   static bool attr_set = false;
   static int ncu = 256;
@@ -407,6 +681,23 @@ int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s) {
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
   hipLaunchKernelGGL(bottleneck64_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_bottleneck64p(const BottleneckArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  static int ncu = 256;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)bottleneck64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES) != hipSuccess) return -7;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      ncu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int want = (a.n_tiles + 7) & ~7;
+  const int grid = want < ncu ? want : (ncu & ~7);
+  hipLaunchKernelGGL(bottleneck64p_kernel, dim3(grid), dim3(256), PLDS_BYTES, s, a);
   return (int)hipGetLastError();
 }
 

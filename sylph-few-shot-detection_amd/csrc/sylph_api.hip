@@ -842,6 +842,36 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
         X = Y;
         continue;
       }
+      // first block of res2 (64 -> 64 -> 64 -> 256, projection folded into conv3's GEMM, stride 1): one fused kernel too
+      if (fuse_bn && dt == DT_BF16 && blk.fused_sc && stride == 1 && mid == 64 && Cin == 64 && cout == 256 &&
+          blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3sc.Cout_pad == 256 && blk.c3sc.Cin == 128 && !blk.c3sc.scale &&
+          (size_t)B * Hin * Win * 512 < ((size_t)1 << 32)) {
+        BottleneckArgs ba;
+        memset(&ba, 0, sizeof(ba));
+        ba.x = X; ba.y = Y;
+        ba.w1 = (const __bf16*)blk.c1.w; ba.w2 = (const __bf16*)blk.c2.w; ba.w3 = (const __bf16*)blk.c3sc.w;
+        ba.s1 = blk.c1.scale; ba.b1 = blk.c1.shift; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
+        ba.s3 = nullptr; ba.b3 = blk.c3sc.shift;
+        ba.zeros = c->zeros;
+        if (!bk_trash) RET(c->dalloc(&bk_trash, (size_t)1024 * 256 * 128));
+        ba.trash = bk_trash;
+        std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
+        std::vector<BkTile> bt;
+        int ph, pw;
+        pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
+        for (size_t si2 = 0; si2 < sg.size(); ++si2)
+          for (int yy = 0; yy < Hin; yy += ph)
+            for (int xx = 0; xx < Win; xx += pw)
+              bt.push_back(BkTile{sg[si2].in_row0, Hin, Win, (yy << 16) | xx, ph, pw, (65536u + pw - 1) / pw, (65536u + pw + 2 - 1) / (pw + 2)});
+        void* btd = nullptr;
+        RET(upload(c, &btd, bt.data(), bt.size() * sizeof(BkTile)));
+        ba.bk = (const BkTile*)btd;
+        ba.n_tiles = (int)bt.size();
+        const double fl = 2.0 * (double)B * Hin * Win * (64.0 * 64 + 64.0 * 576 + 128.0 * 256);
+        ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
+        X = Y; Cin = cout;
+        continue;
+      }
       ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
       RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
       ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
