@@ -203,18 +203,25 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   };
   auto gn_finish = [&](int g, int cc_of_piece) {  // wait for them, transform, write back (branch-free: no cut in the MFMA stream)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(gx), "+v"(gc0), "+v"(gc1), "+v"(gc2), "+v"(gc3));
-    const bool live = (hmask >> g) & 1u;
-    const f32x4v cs[4] = {gc0, gc1, gc2, gc3};
+    const unsigned live = ((hmask >> g) & 1u) ? 0xffffffffu : 0u;  // zero-page lanes (conv padding) keep their zeros
+    const f32x4v cs[4] = {gc0, gc1, gc2, gc3};                      // per channel pair: (a_lo, a_hi, b_lo, b_hi)
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef short s16x2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     u32x4 y;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float lo = fmaf(__uint_as_float(gx[e] << 16), cs[e][0], cs[e][1]);
-      float hi = fmaf(__uint_as_float(gx[e] & 0xffff0000u), cs[e][2], cs[e][3]);
-      if (gn_relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
-      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const f32x2v xv = {__uint_as_float(gx[e] << 16), __uint_as_float(gx[e] & 0xffff0000u)};
+      const f32x2v av = {cs[e][0], cs[e][1]}, bv = {cs[e][2], cs[e][3]};
+      const f32x2v r = __builtin_elementwise_fma(xv, av, bv);
       bf16x2 pk;
-      pk[0] = (bf16_t)lo; pk[1] = (bf16_t)hi;
-      y[e] = live ? *reinterpret_cast<unsigned*>(&pk) : gx[e];  // zero-page lanes keep their zeros
+      pk[0] = (bf16_t)r[0]; pk[1] = (bf16_t)r[1];
+      unsigned u = __builtin_bit_cast(unsigned, pk);
+      if (gn_relu) {  // ReLU on the bf16 pair: packed signed max with 0
+        const s16x2v z = {0, 0};
+        u = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2v, u), z));
+      }
+      y[e] = u & live;
     }
     asm volatile("ds_write_b128 %0, %1" ::"v"(gn_addr(g, cc_of_piece)), "v"(y) : "memory");
   };
@@ -332,10 +339,12 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   loads_on = false;
 #endif
   if (gn_in) {  // (a, b) of both patches' segments -> LDS (plain loads: issued after the DMA queue, waited below)
-    for (int idx = tid; idx < 2 * Cin; idx += PNT) {
-      const int pch = idx >= Cin ? 1 : 0, ch = idx - pch * Cin;
+    // stored per channel PAIR as (a0, a1, b0, b1): the transform is then one packed FMA per bf16 pair
+    for (int idx = tid; idx < Cin; idx += PNT) {
+      const int pch = idx >= Cin / 2 ? 1 : 0, ch = (idx - pch * (Cin / 2)) * 2;
       const int seg = pch ? tl1.x : tl0.x;
-      *reinterpret_cast<float2*>(smem + COEF_OFF + idx * 8) = a.gn_coef[(size_t)seg * a.in_ld + goff + ch];
+      const float2 c0v = a.gn_coef[(size_t)seg * a.in_ld + goff + ch], c1v = a.gn_coef[(size_t)seg * a.in_ld + goff + ch + 1];
+      *reinterpret_cast<float4*>(smem + COEF_OFF + (pch * Cin + ch) * 8) = make_float4(c0v.x, c1v.x, c0v.y, c1v.y);
     }
   }
   HP_WAITV(4);  // halo + phase 0 landed (phases 1, 2 in flight)
