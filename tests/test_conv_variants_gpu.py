@@ -10,6 +10,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -60,3 +61,39 @@ def test_parity_suite_with_fusions_off():
     must pass the same backbone / head / episode checks as the default fused one."""
     _rerun({"SYLPH_FUSE_BOTTLENECK": "0", "SYLPH_FUSE_STEM_POOL": "0", "SYLPH_GN_FUSE": "0"},
            "stem or backbone or head or episode or c3 or full_size_prop")
+
+
+_PYRAMID_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from sylph_amd import synthetic as W
+from test_hip_parity import _engine, _cfg
+B, H, Wd = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+eng = _engine("bf16", _cfg())
+eng.load_state_dict(W.synthetic_state_dict(0, depth=50))
+eng.preprocess(W.synthetic_images(B, H, Wd, seed=11))
+eng.backbone()
+np.savez(sys.argv[3], *[t.float().cpu().numpy() for t in eng.export_pyramid()])
+"""
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 200, 232), (3, 72, 328), (2, 264, 136)])
+def test_fused_backbone_kernels_match_unfused_graph_on_ragged_maps(tmp_path, B, H, W):
+    """bottleneck64(_p)_kernel and stem_pool_kernel against the three-launch / two-launch graph they replace, on maps whose
+    patches are ragged in both directions and whose tile count is not a multiple of the 8-block walk (res2 maps 50x58,
+    18x82, 66x34).  Both builds round to bf16 at the same points, so the pyramids agree to bf16 noise."""
+    outs = {}
+    for name, env_extra in (("fused", {}), ("unfused", {"SYLPH_FUSE_BOTTLENECK": "0", "SYLPH_FUSE_STEM_POOL": "0"})):
+        path = str(tmp_path / f"{name}.npz")
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", _PYRAMID_CHILD, os.path.join(ROOT, "sylph-few-shot-detection_amd"),
+                            os.path.join(ROOT, "tests"), path, str(B), str(H), str(W)], env=env, cwd=ROOT, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        z = np.load(path)
+        outs[name] = [z[k] for k in z.files]
+    for lvl, (a, b) in enumerate(zip(outs["fused"], outs["unfused"])):
+        assert a.shape == b.shape and np.isfinite(a).all()
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        err = np.abs(a - b).max() / max(1.0, np.abs(b).max())
+        assert cos > 0.9995 and err < 0.05, f"level {lvl}: cosine {cos}, max rel err {err}"
