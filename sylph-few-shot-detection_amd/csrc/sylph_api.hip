@@ -215,6 +215,10 @@ struct Plan {
   void *tA = nullptr, *tB = nullptr, *tC = nullptr, *tD = nullptr;
   void* cls_feat = nullptr;  // output of the cls tower (input of the class-conditional conv)
   int cls_ld = 256;
+  // bf16, un-paired towers: the last cls-tower GroupNorm is NOT applied by the head ops; sylph_fcos_head either fuses it into the
+  // class-conditional conv (N <= 32: head_fused.hip) or runs cls_apply first
+  const float2* cls_coef = nullptr;
+  std::function<int(hipStream_t)> cls_apply;
   float* pred = nullptr;    // [rows][8]
   float* logits = nullptr;  // [rows][logits_ld]
   int logits_ld = 0, logits_cap_ld = 0, ncls = 0;
@@ -654,7 +658,8 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
 // coef_out != nullptr: no apply pass; the (a, b) table of this layer's GroupNorm is left for the NEXT conv, which applies
 // it (+ ReLU) to its input halo in LDS (ConvOpts::gn_coef).
 static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
-                       const std::vector<SegDesc>& segs, ConvOpts o, const GNLayer& G, int relu, const float2** coef_out = nullptr) {
+                       const std::vector<SegDesc>& segs, ConvOpts o, const GNLayer& G, int relu, const float2** coef_out = nullptr,
+                       OpFn* apply_out = nullptr) {
   o.want_gn = 1;
   Geom g;
   const int ld = L.Cout, ngroups = L.Cout / 8;
@@ -679,6 +684,10 @@ static int add_conv_gn(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L,
     RET(c->dalloc((void**)&coef, (size_t)nseg * ld * sizeof(float2)));
     ops.push_back([=](hipStream_t s) { return launch_gn_finalize_coef(ngroups, gsd, nseg, partial, stats_ws, ga, be, 1e-5f, coef, s); });
     *coef_out = coef;
+    if (apply_out)  // the stand-alone apply of the same layer, for a consumer that cannot take the coefficients
+      *apply_out = [=](hipStream_t s) {
+        return launch_gn_apply_partials(dt, out, ld, ngroups, gsd, nseg, max_rows, partial, stats_ws, ga, be, 1e-5f, relu, s);
+      };
     return 0;
   }
   ops.push_back([=](hipStream_t s) {
@@ -1003,7 +1012,7 @@ static int build_head(sylph_ctx* c, Plan* P) {
   const std::vector<SegDesc> segs = pyramid_segs(c, P);
   auto& ops = P->head_ops;
   auto tower = [&](const std::vector<ConvLayer>& convs, const std::vector<GNLayer>& gns, void* b0, void* b1,
-                   void** last) -> int {
+                   void** last, bool defer_last) -> int {
     const void* in = P->F;
     void* out = b0;
     // GroupNorm + ReLU of layers 0 .. n-2 are applied by the NEXT layer's conv to its input halo in LDS (conv_hpipe.hip):
@@ -1017,8 +1026,11 @@ static int build_head(sylph_ctx* c, Plan* P) {
       ConvOpts o; o.pad = 1;
       if (coef_prev) { o.gn_coef = coef_prev; o.gn_relu = 1; }
       const float2* coef = nullptr;
-      const bool defer = fuse && i + 1 < convs.size();
-      RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1, defer ? &coef : nullptr));
+      const bool is_last = i + 1 == convs.size();
+      const bool defer = (fuse && !is_last) || (is_last && defer_last);
+      OpFn apply;
+      RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1, defer ? &coef : nullptr, (is_last && defer_last) ? &apply : nullptr));
+      if (is_last && defer_last) { P->cls_coef = coef; P->cls_apply = apply; }
       coef_prev = coef;
       in = out;
       out = (out == b0) ? b1 : b0;
@@ -1053,8 +1065,11 @@ static int build_head(sylph_ctx* c, Plan* P) {
     box_feat = (char*)cls_feat + 256 * e;
     feat_ld = 512;
   } else {
-    RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat));
-    RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat));
+    // the cls tower's last GroupNorm is left to sylph_fcos_head (fused into the class-conditional conv when N <= 32)
+    static const int gn_logits_on = getenv("SYLPH_FUSE_GN_LOGITS") ? atoi(getenv("SYLPH_FUSE_GN_LOGITS")) : 1;
+    P->cls_coef = nullptr; P->cls_apply = nullptr;
+    RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat, gn_logits_on && c->dt == DT_BF16 && !c->cls_tower.empty()));
+    RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat, false));
   }
   P->cls_ld = feat_ld;
   ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
@@ -1861,10 +1876,22 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   RET(ensure_logits(c, P, N));
   RET(run_ops(c, P->head_ops, "fcos_head"));
   KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, c->stream), "pack_codes");
+  const float* bias = (c->cfg.cond_use_bias && cls_bias) ? cls_bias : nullptr;
+  if (P->cls_coef) {
+    if (bn == 32 && P->cls_ld == 256) {  // GroupNorm + ReLU + class-conditional conv in one HBM pass (head_fused.hip)
+      const Plan* PP = P;
+      KCHK(timed_op(c, 2.0 * (double)rows * N * 256.0, c->stream, [=](hipStream_t st) {
+             return launch_gn_logits(PP->cls_feat, 256, PP->cls_coef, PP->code_w, bias, N, PP->logits, Npad, PP->head_segs, PP->head_tiles32,
+                                     PP->head_mtiles32, st);
+           }), "gn_logits");
+      return 0;
+    }
+    KCHK(P->cls_apply(c->stream), "gn_apply (cls tower, last layer)");
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = P->cls_feat; a.wt = P->code_w; a.out = P->logits;
-  a.shift = (c->cfg.cond_use_bias && cls_bias) ? cls_bias : nullptr;
+  a.shift = bias;
   a.zeros = c->zeros; a.tap_dy = 1;
   a.segs = P->head_segs;
   int BM = P->head_BM;

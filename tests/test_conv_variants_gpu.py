@@ -59,7 +59,7 @@ def test_parity_suite_with_halo_mode_forced():
 def test_parity_suite_with_fusions_off():
     """The unfused graph (res2 identity blocks as three launches, stem and max-pool as two, stand-alone GroupNorm applies)
     must pass the same backbone / head / episode checks as the default fused one."""
-    _rerun({"SYLPH_FUSE_BOTTLENECK": "0", "SYLPH_FUSE_STEM_POOL": "0", "SYLPH_GN_FUSE": "0"},
+    _rerun({"SYLPH_FUSE_BOTTLENECK": "0", "SYLPH_FUSE_STEM_POOL": "0", "SYLPH_GN_FUSE": "0", "SYLPH_FUSE_GN_LOGITS": "0"},
            "stem or backbone or head or episode or c3 or full_size_prop")
 
 
