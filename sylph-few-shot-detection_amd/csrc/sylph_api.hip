@@ -140,6 +140,7 @@ struct sylph_ctx {
   std::vector<GNLayer> pair_gn;
   bool paired = false;
   ConvLayer pred;  // bbox_pred(4) + ctrness(1) + iou_overlap(1)
+  void* pred_taps = nullptr;  // bf16 [64][256]: row kh * sw + kw * Cout + n = pred weight W[n][kh][kw][:] (head_fused.hip), bf16 mode only
   std::vector<float> level_scales;
   std::vector<ConvLayer> cg_tower;
   std::vector<GNLayer> cg_gn;
@@ -1012,7 +1013,8 @@ static int build_head(sylph_ctx* c, Plan* P) {
   const std::vector<SegDesc> segs = pyramid_segs(c, P);
   auto& ops = P->head_ops;
   auto tower = [&](const std::vector<ConvLayer>& convs, const std::vector<GNLayer>& gns, void* b0, void* b1,
-                   void** last, bool defer_last) -> int {
+                   void** last, const float2** coef_last, OpFn* apply_last) -> int {
+    const bool defer_last = coef_last != nullptr;
     const void* in = P->F;
     void* out = b0;
     // GroupNorm + ReLU of layers 0 .. n-2 are applied by the NEXT layer's conv to its input halo in LDS (conv_hpipe.hip):
@@ -1030,7 +1032,7 @@ static int build_head(sylph_ctx* c, Plan* P) {
       const bool defer = (fuse && !is_last) || (is_last && defer_last);
       OpFn apply;
       RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1, defer ? &coef : nullptr, (is_last && defer_last) ? &apply : nullptr));
-      if (is_last && defer_last) { P->cls_coef = coef; P->cls_apply = apply; }
+      if (is_last && defer_last) { *coef_last = coef; *apply_last = apply; }
       coef_prev = coef;
       in = out;
       out = (out == b0) ? b1 : b0;
@@ -1040,6 +1042,9 @@ static int build_head(sylph_ctx* c, Plan* P) {
   };
   void *cls_feat = nullptr, *box_feat = nullptr;
   int feat_ld = 256;
+  const float2* box_coef = nullptr;
+  OpFn box_apply;
+  bool box_defer = false;
   if (c->paired) {
     // tA|tB and tC|tD are used as two [rows][512] ping-pong buffers.  The towers run image-chunk by
     // image-chunk (depth first): a chunk's [rows][512] layer output (~23 MB per 800x1344 image) is
@@ -1068,12 +1073,35 @@ static int build_head(sylph_ctx* c, Plan* P) {
     // the cls tower's last GroupNorm is left to sylph_fcos_head (fused into the class-conditional conv when N <= 32)
     static const int gn_logits_on = getenv("SYLPH_FUSE_GN_LOGITS") ? atoi(getenv("SYLPH_FUSE_GN_LOGITS")) : 1;
     P->cls_coef = nullptr; P->cls_apply = nullptr;
-    RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat, gn_logits_on && c->dt == DT_BF16 && !c->cls_tower.empty()));
-    RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat, false));
+    const bool defer = gn_logits_on && c->dt == DT_BF16;
+    OpFn cls_apply;
+    RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat, (defer && !c->cls_tower.empty()) ? &P->cls_coef : nullptr, &cls_apply));
+    P->cls_apply = cls_apply;
+    box_defer = defer && c->pred_taps && !c->box_tower.empty();
+    RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat, box_defer ? &box_coef : nullptr, &box_apply));
   }
   P->cls_ld = feat_ld;
-  ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
-  RET(add_conv(c, ops, c->pred, box_feat, feat_ld, P->pred, 8, segs, op));
+  Geom g32;  // 128-row pointwise tiles of the pyramid (class-conditional conv with N <= 32, fused GN + prediction pass)
+  RET(make_geom(c, segs, 128, &g32));
+  if (box_defer && box_coef) {
+    // last bbox-tower GroupNorm + the 3x3 prediction convs: one streaming pass for the nine tap responses + a gather (head_fused.hip)
+    const int cp = c->pred.Cout, sw = (3 * cp + 3) & ~3;
+    float* taps_ws = nullptr;
+    const size_t plane_rows = rows;
+    RET(c->dalloc((void**)&taps_ws, (size_t)3 * rows * sw * sizeof(float)));
+    const void *xin = box_feat, *wt = c->pred_taps;
+    const float* bias = c->pred.shift;
+    float* pout = P->pred;
+    const SegDesc* sgd = g32.segs; const int2* tld = g32.tiles; const int ntl = g32.n_mtiles;
+    const float2* bc = box_coef;
+    const double fl = 2.0 * (double)rows * cp * 9.0 * 256.0;
+    ops.push_back([=](hipStream_t s) {
+      return timed_op(c, fl, s, [=](hipStream_t st) { return launch_gn_pred_taps(xin, 256, bc, wt, cp, bias, 4, 4, taps_ws, plane_rows, pout, 8, sgd, tld, ntl, st); });
+    });
+  } else {
+    ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
+    RET(add_conv(c, ops, c->pred, box_feat, feat_ld, P->pred, 8, segs, op));
+  }
   // geometry for the class-conditional 1x1 conv (weights arrive per call)
   {
     Geom g;
@@ -1081,8 +1109,6 @@ static int build_head(sylph_ctx* c, Plan* P) {
     conv_pick_tile((int)rows, 128, 9, &BM, &BN);  // geometry for BN in {64,128}; BM from the 128-wide rule
     RET(make_geom(c, segs, BM, &g));
     P->head_segs = g.segs; P->head_tiles = g.tiles; P->head_mtiles = g.n_mtiles; P->head_BM = BM;
-    Geom g32;
-    RET(make_geom(c, segs, 128, &g32));
     P->head_tiles32 = g32.tiles; P->head_mtiles32 = g32.n_mtiles;
   }
   P->cls_feat = cls_feat;
@@ -1529,6 +1555,24 @@ int sylph_finalize_weights(sylph_ctx* c) {
       c->paired = true;
     }
     RET(make_conv_bias(c, {hp + ".bbox_pred", hp + ".ctrness", hp + ".iou_overlap"}, &c->pred));
+    c->pred_taps = nullptr;
+    if (c->dt == DT_BF16 && c->pred.KH == 3 && c->pred.KW == 3 && c->pred.Cin == 256 && 3 * ((3 * c->pred.Cout + 3) & ~3) <= 64) {
+      // the same weights stacked for the fused GroupNorm + prediction pass: row kh * sw + kw * Cout + n, sw = roundup4(3 * Cout)
+      const int cp = c->pred.Cout, sw = (3 * cp + 3) & ~3;
+      std::vector<uint16_t> tw((size_t)64 * 256, 0);
+      int n0 = 0;
+      for (const char* nm : {".bbox_pred", ".ctrness", ".iou_overlap"}) {
+        const HostTensor* w = find_w(c, hp + nm + ".weight");
+        if (!w) continue;
+        const int co = (int)w->shape[0];
+        for (int n = 0; n < co; ++n)
+          for (int ci = 0; ci < 256; ++ci)
+            for (int tap = 0; tap < 9; ++tap)
+              tw[(size_t)((tap / 3) * sw + (tap % 3) * cp + n0 + n) * 256 + ci] = f2bf_host(w->data[((size_t)n * 256 + ci) * 9 + tap]);
+        n0 += co;
+      }
+      RET(upload(c, &c->pred_taps, tw.data(), tw.size() * 2));
+    }
     c->level_scales.assign(c->cfg.nlevels, 1.f);
     if (c->cfg.use_scale)
       for (int l = 0; l < c->cfg.nlevels; ++l) {
