@@ -253,7 +253,7 @@ def main():
         achieved = alg_flops / conv_s / 1e12 if conv_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic_per_launch(B, launches // max(args.steps, 1))
         roofline = {
-            "kernel": "conv_igemm_kernel + conv_hpipe_kernel + bottleneck64_kernel (+ stem_conv_kernel): implicit-GEMM MFMA convs, every conv launch of the timed region",
+            "kernel": "conv_hpipe_kernel + conv_igemm_kernel + bottleneck64[p]_kernel + stem_pool_kernel + gn_logits / gn_taps: the MFMA conv launches (and the fused passes that replace convs) of the timed region",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
             "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
             "traffic": traffic, "traffic_source": traffic_src,

@@ -136,14 +136,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   auto issue_x = [&](const i32x8 d) {
     const int row0 = d[0], H = d[1], W = d[2], oy0 = d[3] >> 16, ox0 = d[3] & 0xffff, HW2 = d[5] + 2, HR = (d[4] + 2) * HW2;
     const int nr = (HR + 7) >> 3;  // rows >= HR are never read by P2
-    int hy = 0, hx = xr;           // xr < 8 <= HW2
+    int hy = 0, hx = xr;
     for (int r = 0; r < nr; ++r) {
+      while (hx >= HW2) { hx -= HW2; ++hy; }  // (a single step for patches at least 6 wide; narrow maps may wrap twice)
       const int h = r * 8 + xr;
       const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
       const unsigned off = ((unsigned)(row0 + iy * W + ix) << 9) + (unsigned)((xs ^ (h & 31)) << 4);  // bytes; x < 4 GiB (checked by the host)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(xb + r * 4096 + wave * 1024), 16, 0, 0);
       hx += 8;
-      if (hx >= HW2) { hx -= HW2; ++hy; }
     }
   };
 

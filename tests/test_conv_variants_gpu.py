@@ -77,7 +77,7 @@ np.savez(sys.argv[3], *[t.float().cpu().numpy() for t in eng.export_pyramid()])
 """
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 200, 232), (3, 72, 328), (2, 264, 136)])
+@pytest.mark.parametrize("B,H,W", [(1, 200, 232), (3, 72, 328), (2, 264, 136), (2, 40, 56)])
 def test_fused_backbone_kernels_match_unfused_graph_on_ragged_maps(tmp_path, B, H, W):
     """bottleneck64(_p)_kernel and stem_pool_kernel against the three-launch / two-launch graph they replace, on maps whose
     patches are ragged in both directions and whose tile count is not a multiple of the 8-block walk (res2 maps 50x58,
