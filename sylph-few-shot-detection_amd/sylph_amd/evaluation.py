@@ -158,12 +158,13 @@ def inference_on_dataset_with_class_codes(model, data_loader, evaluator, class_c
     "meta_learn_test_instance") per query batch, evaluator.process(inputs, outputs), evaluator.evaluate()."""
     devices = get_world_size()
     if eval_with_pretrained_code:
-        raise NotImplementedError("eval_with_pretrained_code is out of scope (needs the base detector's cls_logits)")
-    assert class_codes is not None
+        assert class_codes is None  # meta_learn_evaluation.py:376-378: the model's own cls_logits are the codes
+    else:
+        assert class_codes is not None
     if cls_reweight:
         raise NotImplementedError("cls_reweight is not supported (CLS_REWEIGHT is False in every yaml)")
     total = len(data_loader)
-    logger.info(f"Start inference with predicted class codes on {total} images")
+    logger.info(f"Start inference with {'pretrained' if eval_with_pretrained_code else 'predicted'} class codes on {total} images")
     evaluator = evaluator if evaluator is not None else _NoOpEvaluator()
     evaluator.reset()
     num_warmup = min(5, max(total - 1, 0))

@@ -128,6 +128,10 @@ class MetaOneStageDetector(nn.Module):
         """Accepts the reference checkpoint's ["model"] dict (SURVEY.md 8b key layout)."""
         self.engine.load_state_dict(state_dict)
         self._weights_loaded = True
+        # the base detector's own classifier (fcos.py:418-427): kept for eval_with_pretrained_code (class_code=None)
+        w = state_dict.get("proposal_generator.fcos_head.cls_logits.weight")
+        b = state_dict.get("proposal_generator.fcos_head.cls_logits.bias")
+        self._pretrained_cls_logits = (torch.as_tensor(w).float(), torch.as_tensor(b).float()) if w is not None and b is not None else None
         return self
 
     def load_checkpoint(self, path: str):
@@ -218,7 +222,18 @@ class MetaOneStageDetector(nn.Module):
         assert self.episodic_learning
         assert not self.training, "Not for training"
         if class_codes is None:
-            raise NotImplementedError("evaluation with pretrained class codes (class_code=None) is out of scope")
+            # MetaFCOSHead.forward with support_set_per_class_code=None -> forward_base_train (fcos.py:543-578):
+            # logits = self.cls_logits(cls_tower), the pretrained base-class classifier.  A 1x1 cls_logits conv (the
+            # CLS_LOGITS_KERNEL_SIZE of the Meta-FCOS recipes) is exactly the class-conditional conv with fixed codes.
+            pre = getattr(self, "_pretrained_cls_logits", None)
+            if pre is None:
+                raise ValueError("class_code is None and the checkpoint has no proposal_generator.fcos_head.cls_logits weights")
+            if pre[0].dim() != 4 or pre[0].shape[2:] != (1, 1):
+                raise NotImplementedError(f"pretrained cls_logits with kernel {tuple(pre[0].shape[2:])}: only 1x1 "
+                                          "(MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 1) is supported")
+            if not bool(self.cfg.MODEL.META_LEARN.CODE_GENERATOR.USE_BIAS):
+                raise NotImplementedError("pretrained cls_logits needs the bias path of the class-conditional conv (USE_BIAS)")
+            class_codes = {"cls_conv": pre[0].to(self.device), "cls_bias": pre[1].to(self.device)}
         w, b = class_codes["cls_conv"], class_codes.get("cls_bias")
         assert w.dim() == 4, f"Weight has dimension: {w.dim()}"
         assert w.size(1) == 256

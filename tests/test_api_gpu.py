@@ -292,3 +292,36 @@ def test_result_sink_on_model_outputs(model, sd):
     assert t.is_cuda and t.shape == (len(want), 8)
     g = gather_detection_rows(t, capacity=len(want) + 5)
     assert len(detection_rows_to_coco(g)) == len(want)
+
+
+def test_eval_with_pretrained_code_uses_the_checkpoints_cls_logits(model, sd):
+    """class_code=None (meta_learn_evaluation.py:376-378 eval_with_pretrained_code) -> MetaFCOSHead.forward_base_train:
+    logits = cls_logits(cls_tower) with the checkpoint's own 1x1 classifier.  Must equal the class-conditional path fed with
+    those weights as codes, and a plain fp32 conv of the oracle's cls-tower output."""
+    from oracle import backbone as OB, head as OH
+    from sylph_amd import synthetic as W
+    from sylph_amd.evaluation import inference_on_dataset_with_class_codes
+    w = sd["proposal_generator.fcos_head.cls_logits.weight"]
+    b = sd["proposal_generator.fcos_head.cls_logits.bias"]
+    assert w.shape[2:] == (1, 1)
+    imgs = W.synthetic_images(2, 96, 128, seed=21)
+    batch = [{"image": im, "height": 96, "width": 128, "image_id": i} for i, im in enumerate(imgs)]
+    a = model(batch, class_code=None, run_type="meta_learn_test_instance")
+    e = model(batch, class_code={"cls_conv": w.cuda(), "cls_bias": b.cuda()}, run_type="meta_learn_test_instance")
+    for x, y in zip(a, e):
+        assert torch.equal(x["instances"].pred_boxes.tensor, y["instances"].pred_boxes.tensor)
+        assert torch.equal(x["instances"].scores, y["instances"].scores)
+        assert torch.equal(x["instances"].pred_classes, y["instances"].pred_classes)
+    # the logits of the pretrained path against the oracle's tower + an fp32 conv2d with the same weights
+    got = model.engine.export_head()[0]
+    x0, _ = OB.preprocess(imgs)
+    feats = OB.backbone_fpn(x0, sd, 50)
+    for l in range(5):
+        t = OH.tower(feats[l], sd, "proposal_generator.fcos_head.cls_tower")
+        ref = torch.nn.functional.conv2d(t, w, b)
+        assert (got[l].cpu() - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+    col = _Collect()
+    res = inference_on_dataset_with_class_codes(model, [batch], col, None, eval_with_pretrained_code=True)
+    assert res == {"n": 2}
+    with pytest.raises(AssertionError):
+        inference_on_dataset_with_class_codes(model, [batch], col, {"cls_conv": w}, eval_with_pretrained_code=True)
