@@ -63,6 +63,15 @@ def config_from_cfg(cfg) -> SylphConfig:
     else:
         raise NotImplementedError(f"MODEL.FCOS.BOX_QUALITY {bq}")
     sc.prior_prob = float(f.PRIOR_PROB)
+    if int(m.RESNETS.get("RES5_DILATION", 1)) != 1:
+        raise NotImplementedError("MODEL.RESNETS.RES5_DILATION != 1 is not supported")
+    if not bool(m.META_LEARN.EPISODIC_LEARNING):
+        # plain base detector (meta_one_stage_detector.py:52-58: no code generator is built): the head runs the checkpoint's
+        # own 1x1 cls_logits through the class-conditional conv, always with its bias
+        if int(f.get("CLS_LOGITS_KERNEL_SIZE", 3)) != 1:
+            raise NotImplementedError("base-detector inference needs MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 1")
+        sc.cond_use_bias = 1
+        return sc
     cg = m.META_LEARN.CODE_GENERATOR
     # knobs that change the reference arithmetic and are not implemented must fail loudly, not be ignored
     if int(m.RESNETS.get("RES5_DILATION", 1)) != 1:

@@ -90,10 +90,11 @@ def build_code_generator(cfg, feature_channels, feature_levels, strides):
 @META_ARCH_REGISTRY.register()
 class MetaOneStageDetector(nn.Module):
     """Four inference forward types (meta_one_stage_detector.py:415-455):
-      run_type None                         -> NotImplementedError for an episodic model (as the reference)
+      run_type None                         -> forward_base_detector for a non-episodic model (plain FCOS with the checkpoint's
+                                               cls_logits); NotImplementedError for an episodic model (as the reference)
       "meta_learn_test_support"             -> forward_class_code
       "meta_learn_normalize_code"           -> normalize_class_code
-      "meta_learn_test_instance"            -> forward_instances
+      "meta_learn_test_instance"            -> forward_instances (class_code None: evaluation with the pretrained cls_logits)
     Training is out of scope: calling the model in training mode raises NotImplementedError."""
 
     def __init__(self, cfg, dtype: Optional[str] = None, device_index: Optional[int] = None):
@@ -144,8 +145,9 @@ class MetaOneStageDetector(nn.Module):
         if self.training:
             raise NotImplementedError("training is out of scope of the MI355X inference path; call model.eval()")
         if run_type is None:
+            # MetaProposalNetwork.forward (meta_one_stage_detector.py:120-141): a non-episodic model is a plain base detector
             if not self.episodic_learning:
-                raise NotImplementedError("base-detector inference (EPISODIC_LEARNING False) is out of scope")
+                return self.forward_base_detector(batched_inputs)
             raise NotImplementedError(
                 "Episodic learning inferrence for image and features is not supported in forward.")
         if run_type == "meta_learn_test_support":
@@ -217,9 +219,18 @@ class MetaOneStageDetector(nn.Module):
         return codes
 
     # ---- query path ----------------------------------------------------------------------------------
+    def forward_base_detector(self, batched_inputs: List[Dict[str, Any]]):
+        """meta_one_stage_detector.py:298-323 (inference branch) + the {"proposals"} -> {"instances"} renaming of
+        MetaOneStageDetector.forward (:436-441): FCOS with the checkpoint's own cls_logits."""
+        assert not self.episodic_learning
+        return self._detect(batched_inputs, None)
+
     def forward_instances(self, batched_inputs: List[Dict[str, Any]], class_codes: Dict[str, torch.Tensor]):
         """meta_one_stage_detector.py:261-296 -> [{"instances": Instances}] at input["height"/"width"] scale."""
         assert self.episodic_learning
+        return self._detect(batched_inputs, class_codes)
+
+    def _detect(self, batched_inputs: List[Dict[str, Any]], class_codes):
         assert not self.training, "Not for training"
         if class_codes is None:
             # MetaFCOSHead.forward with support_set_per_class_code=None -> forward_base_train (fcos.py:543-578):
@@ -231,7 +242,7 @@ class MetaOneStageDetector(nn.Module):
             if pre[0].dim() != 4 or pre[0].shape[2:] != (1, 1):
                 raise NotImplementedError(f"pretrained cls_logits with kernel {tuple(pre[0].shape[2:])}: only 1x1 "
                                           "(MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 1) is supported")
-            if not bool(self.cfg.MODEL.META_LEARN.CODE_GENERATOR.USE_BIAS):
+            if self.episodic_learning and not bool(self.cfg.MODEL.META_LEARN.CODE_GENERATOR.USE_BIAS):
                 raise NotImplementedError("pretrained cls_logits needs the bias path of the class-conditional conv (USE_BIAS)")
             class_codes = {"cls_conv": pre[0].to(self.device), "cls_bias": pre[1].to(self.device)}
         w, b = class_codes["cls_conv"], class_codes.get("cls_bias")

@@ -325,3 +325,37 @@ def test_eval_with_pretrained_code_uses_the_checkpoints_cls_logits(model, sd):
     assert res == {"n": 2}
     with pytest.raises(AssertionError):
         inference_on_dataset_with_class_codes(model, [batch], col, {"cls_conv": w}, eval_with_pretrained_code=True)
+
+
+def test_base_detector_inference_run_type_none(sd):
+    """run_type=None on a NON-episodic model = MetaProposalNetwork.forward_base_detector (meta_one_stage_detector.py:298-323,
+    436-441): plain FCOS with the checkpoint's cls_logits; no code generator is built or needed.  Must give the detections of
+    the episodic model fed with the same weights as class codes."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.runner import MetaFCOSRunner
+    r = MetaFCOSRunner()
+    cfg = r.get_default_cfg()
+    cfg.MODEL.META_LEARN.EPISODIC_LEARNING = False
+    cfg.MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 1
+    cfg.MODEL.FCOS.NUM_CLASSES = int(sd["proposal_generator.fcos_head.cls_logits.weight"].shape[0])
+    base = r.build_model(cfg, dtype="f32")
+    assert base.code_generator is None
+    base.load_state_dict({k: v for k, v in sd.items() if not k.startswith("code_generator.")})
+    base.eval()
+    imgs = W.synthetic_images(2, 96, 128, seed=22)
+    batch = [{"image": im, "height": 96, "width": 128} for im in imgs]
+    got = base(batch)
+    runner, ecfg = _cfg()
+    epi = runner.build_model(ecfg, dtype="f32")
+    epi.load_state_dict(sd)
+    epi.eval()
+    w, b = sd["proposal_generator.fcos_head.cls_logits.weight"], sd["proposal_generator.fcos_head.cls_logits.bias"]
+    exp = epi(batch, class_code={"cls_conv": w.cuda(), "cls_bias": b.cuda()}, run_type="meta_learn_test_instance")
+    assert len(got) == 2
+    for x, y in zip(got, exp):
+        assert torch.equal(x["instances"].pred_boxes.tensor, y["instances"].pred_boxes.tensor)
+        assert torch.equal(x["instances"].scores, y["instances"].scores)
+    with pytest.raises(AssertionError):
+        base(batch, class_code={"cls_conv": w.cuda(), "cls_bias": b.cuda()}, run_type="meta_learn_test_instance")
+    with pytest.raises(NotImplementedError):
+        epi(batch)  # episodic models refuse run_type=None like the reference
