@@ -56,7 +56,6 @@ struct ConvArgs {
   int tap_dy;                 // input rows advanced per kernel-row tap (1; stem: rows per K-slice)
   const float2* gn_coef;      // conv_hpipe.hip: fused GroupNorm(+ReLU) of the INPUT: per (segment, input channel) (a, b),
   int gn_relu;                //   x <- relu?(a * x + b) applied to the landed halo in LDS; row stride of gn_coef = in_ld
-  int stagger;                // conv_hpipe: start-up delay step (units of 64 clocks) of the first block on every CU, see conv_hpipe.hip
 };
 
 // fused identity bottleneck (bottleneck.hip): x, y [pos][256] bf16; w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16
@@ -127,8 +126,6 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
 // table then holds PAIRS of patches and n_mtiles counts the pairs)
 bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a);
 int launch_conv_hpipe(const ConvArgs& a, hipStream_t s);
-bool conv_hq_ok(const ConvArgs& a);                      // conv_hpipe4.hip: same tile and LDS images with four 128 x 128 wave tiles
-int launch_conv_hq(const ConvArgs& a, hipStream_t s);
 int launch_hpipe_pack_weights(const void* w_igemm, void* w_hpipe, int Cout, int Cin, hipStream_t s);  // a.wt of an hpipe launch
 int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s);   // bottleneck.hip: identity block, persistent, weights in registers
 int launch_bottleneck64p(const BottleneckArgs& a, hipStream_t s);  // first block of res2: x [pos][64], w3 = [256][128] packed [W3 | Wsc], y = relu(acc + b3)

@@ -106,14 +106,6 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   const int mt = xcd * chunk + m_local;
   if (m_local >= chunk || mt >= a.n_mtiles) return;
 
-  // Start-up stagger.  All blocks of a launch take the same time, one block per CU: left alone, all 256 CUs reach their epilogue
-  // in the same microsecond and the 33.5 MB of output tiles of a round go out as ONE burst (6.7 us at HBM rate, measured: the
-  // epilogue cost 118 us of a 1 129-us launch) while every MFMA pipe idles.  Delaying the FIRST block of each CU by a different
-  // amount (32 steps per XCD) spreads the write-outs of all later rounds over a window the HBM can absorb in the background.
-  if (a.stagger > 0 && L < 256) {
-    const int steps = ((L >> 3) & 31) * a.stagger;
-    for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(1);
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -402,113 +394,100 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-page tail loads must not land in the epilogue tile
   __syncthreads();
 
-  // ---- fused epilogue ------------------------------------------------------------------------------------------------
-  // A wave owns a whole patch (128 positions) x 64 channels, and the D^T MFMA layout leaves a lane with 4 CONSECUTIVE channels
-  // (32 j + 8 q + 4 lh .. + 3) of position i * 32 + l31.  FrozenBN / bias, ReLU, the GroupNorm partial sums and the bf16
-  // rounding happen in registers; the partial of a (patch, 8-channel group) is a butterfly over the lanes of ONE wave.  The
-  // bf16 tile then takes a WAVE-PRIVATE trip through LDS (64 positions x 64 channels at a time, 9 KiB per wave, no block
-  // barrier) only to turn the 8-byte-per-lane fragments into 16-byte-per-lane row segments: 8 lanes write one 128-byte line.
-  // (The previous epilogue staged fp32 through LDS block-wide: four passes, eight barriers, ~240 VALU instructions per thread
-  //  and 512 KiB of LDS traffic per tile = 6.7 us per tile, 118 us of a 1 129-us FPN P3 launch.  Storing the fragments
-  //  directly -- 16 contiguous bytes per position and instruction -- was slower still: partial-line writes.)
+  // ---- fused epilogue: per patch two 64-row passes through an fp32 LDS tile ---------------------------------------
+  float* const sC = reinterpret_cast<float*>(smem);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  constexpr int EP = 144;                       // staging pitch: 64 channels bf16 + 16 B
-  char* const stg = smem + wave * (64 * EP);    // 8 x 9 216 B
-  const SegDesc& sp = wm ? sd1 : sd0;
-  const int ty = wm ? tl1.y : tl0.y;
-  const int oy0 = ty >> 16, ox0 = ty & 0xffff;
-  const int PW = sp.pw, NPOS = sp.ph * sp.pw;
-  const int cb = nt * 256 + wn * 64;            // first channel of this wave
+  const int c8 = tid & 31, rr = tid >> 5;
+  const int n0 = nt * 256 + c8 * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 s4v = a.scale ? reinterpret_cast<const float4*>(a.scale + n0)[h] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 b4v = a.shift ? reinterpret_cast<const float4*>(a.shift + n0)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[4 * h] = s4v.x; sc[4 * h + 1] = s4v.y; sc[4 * h + 2] = s4v.z; sc[4 * h + 3] = s4v.w;
+    sh[4 * h] = b4v.x; sh[4 * h + 1] = b4v.y; sh[4 * h + 2] = b4v.z; sh[4 * h + 3] = b4v.w;
+  }
   const bool relu = a.relu_nch > 0;
-  float gs1[2][4], gs2[2][4], gpv[2][4];
-  float4 scv[2][4], shv[2][4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int pp = 0; pp < 2; ++pp) {  // patch
+    const SegDesc& sp = pp ? sd1 : sd0;
+    const int ty = pp ? tl1.y : tl0.y;
+    const int oy0 = ty >> 16, ox0 = ty & 0xffff;
+    const int PW = sp.pw, NPOS = sp.ph * sp.pw;
+    bf16_t* __restrict__ outn = out + (size_t)sp.out_row0 * a.out_ld + n0;
+    // GroupNorm partial sums of this patch about a pivot every lane of a group shares (the conv bias of the group's first
+    // channel: what makes |mean| >> sigma in practice), so that lanes and waves merge by plain additions
+    float gn_n = 0.f, gn_s1 = 0.f, gn_s2 = 0.f;
+    const float gn_pv = sh[0];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      gs1[j][q] = 0.f; gs2[j][q] = 0.f;
-      const int n = cb + 32 * j + 8 * q;
-      // pivot of the shifted sums: the conv bias / BN shift of the group's first channel (what makes |mean| >> sigma in practice)
-      gpv[j][q] = a.shift ? a.shift[n] : 0.f;
-      scv[j][q] = a.scale ? *reinterpret_cast<const float4*>(a.scale + n + 4 * lh) : make_float4(1.f, 1.f, 1.f, 1.f);
-      shv[j][q] = a.shift ? *reinterpret_cast<const float4*>(a.shift + n + 4 * lh) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  float cnt = 0.f;
-  // read-back role of this lane: 16-byte chunk rc of staging row rr0 + 8 it
-  const int rr0 = lane >> 3, rc = lane & 7;
+    for (int hp = 0; hp < 2; ++hp) {  // 64-row half of the patch
+      if (pp + hp > 0) lds_barrier();
+      if (wm == pp) {
 #pragma unroll
-  for (int hp = 0; hp < 2; ++hp) {  // 64-position half of the patch
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int i = 2 * hp + ii;
-      const int m = i * 32 + l31;
-      const int my = (int)(((unsigned)m * sp.inv_pw) >> 16);
-      const bool valid = m < NPOS && oy0 + my < sp.out_H && ox0 + (m - my * PW) < sp.out_W;
-      cnt += valid ? 1.f : 0.f;
-      char* wp = stg + (ii * 32 + l31) * EP + 8 * lh;
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+            for (int g = 0; g < 4; ++g) {
+              const f32x16& c = acc[2 * hp + ii][j];
+              *reinterpret_cast<float4*>(sC + (ii * 32 + l31) * SCP + wn * 64 + j * 32 + 8 * g + 4 * lh) =
+                  make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
+            }
+      }
+      lds_barrier();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 s4v = scv[j][q], b4v = shv[j][q];
-          float v[4] = {acc[i][j][4 * q] * s4v.x + b4v.x, acc[i][j][4 * q + 1] * s4v.y + b4v.y, acc[i][j][4 * q + 2] * s4v.z + b4v.z,
-                        acc[i][j][4 * q + 3] * s4v.w + b4v.w};
+      for (int it = 0; it < 4; ++it) {
+        const int rl = rr + 16 * it;
+        const int m = hp * 64 + rl;
+        const int my = (int)(((unsigned)m * sp.inv_pw) >> 16);
+        const int oy = oy0 + my, ox = ox0 + (m - my * PW);
+        if (m < NPOS && oy < sp.out_H && ox < sp.out_W) {
+          float v[8];
+          const float4 lo = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(sC + rl * SCP + c8 * 8 + 4);
+          v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
           if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          if (a.gn_partial && valid) {
+          if (a.gn_partial) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[e] - gpv[j][q]; gs1[j][q] += d; gs2[j][q] = fmaf(d, d, gs2[j][q]); }
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - gn_pv; gn_s1 += d; gn_s2 = fmaf(d, d, gn_s2); }
+            gn_n += 8.f;
           }
-          bf16x2 lo, hi;
-          lo[0] = (bf16_t)v[0]; lo[1] = (bf16_t)v[1]; hi[0] = (bf16_t)v[2]; hi[1] = (bf16_t)v[3];
-          const u32x2 o = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-          *reinterpret_cast<u32x2*>(wp + 64 * j + 16 * q) = o;
-        }
-    }
-    // same-wave LDS traffic is ordered: no barrier between the writes above and the reads below
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = rr0 + 8 * it, m = hp * 64 + r;
-      const int my = (int)(((unsigned)m * sp.inv_pw) >> 16);
-      const int oy = oy0 + my, ox = ox0 + (m - my * PW);
-      const u32x4v vv = *reinterpret_cast<const u32x4v*>(stg + r * EP + rc * 16);
-#ifdef HP_NOEPI
-      if (m < NPOS && oy < sp.out_H && ox < sp.out_W && vv[0] == 0x12345678u)
+#ifndef HP_NOEPI
+          store8<bf16_t>(outn + (size_t)(oy * sp.out_W + ox) * a.out_ld, v);
 #else
-      if (m < NPOS && oy < sp.out_H && ox < sp.out_W)
+          if (v[0] == 1234.5f) store8<bf16_t>(outn + (size_t)(oy * sp.out_W + ox) * a.out_ld, v);
 #endif
-        *reinterpret_cast<u32x4v*>(out + ((size_t)sp.out_row0 + (size_t)(oy * sp.out_W + ox)) * a.out_ld + cb + rc * 8) = vv;
-    }
-  }
-  if (a.gn_partial) {  // one (n, mean, M2) partial per patch and 8-channel group: butterfly over the 64 lanes, fixed order
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-      cnt += __shfl_xor(cnt, sft);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          gs1[j][q] += __shfl_xor(gs1[j][q], sft);
-          gs2[j][q] += __shfl_xor(gs2[j][q], sft);
         }
+      }
     }
-    if (lane == 0) {
-      // every valid position was counted by its lh = 0 and lh = 1 lane: N = positions x 8 channels = cnt * 4
-      const float N = cnt * 4.f, inv_n = N > 0.f ? 1.f / N : 0.f;
+    if (a.gn_partial) {  // one (n, mean, M2) partial per patch and 8-channel group, merged in a fixed order
+      gn_n += __shfl_xor(gn_n, 32);  // lanes c8 and c8 + 32 of a wave hold the same group (rows rr, rr + 1)
+      gn_s1 += __shfl_xor(gn_s1, 32);
+      gn_s2 += __shfl_xor(gn_s2, 32);
+      lds_barrier();
+      float* red = sC;  // [8 waves][32 groups][3]
+      if (lane < 32) {
+        red[(wave * 32 + c8) * 3 + 0] = gn_n;
+        red[(wave * 32 + c8) * 3 + 1] = gn_s1;
+        red[(wave * 32 + c8) * 3 + 2] = gn_s2;
+      }
+      lds_barrier();
+      if (tid < 32) {
+        float N = 0.f, S1 = 0.f, S2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float S1 = gs1[j][q], S2 = gs2[j][q];
-          const float m2 = S2 - S1 * S1 * inv_n;
-          float* gp = a.gn_partial + ((size_t)(2 * mt + wm) * (a.Cout >> 3) + ((cb + 32 * j + 8 * q) >> 3)) * 3;
-          gp[0] = N; gp[1] = gpv[j][q] + S1 * inv_n; gp[2] = m2 > 0.f ? m2 : 0.f;
+        for (int w = 0; w < 8; ++w) {
+          N += red[(w * 32 + c8) * 3 + 0]; S1 += red[(w * 32 + c8) * 3 + 1]; S2 += red[(w * 32 + c8) * 3 + 2];
         }
+        const float inv_n = N > 0.f ? 1.f / N : 0.f;
+        const float m2 = S2 - S1 * S1 * inv_n;
+        float* gp = a.gn_partial + ((size_t)(2 * mt + pp) * (a.Cout >> 3) + (n0 >> 3)) * 3;
+        gp[0] = N; gp[1] = gn_pv + S1 * inv_n; gp[2] = m2 > 0.f ? m2 : 0.f;
+      }
     }
   }
 }
@@ -549,12 +528,8 @@ int launch_conv_hpipe(const ConvArgs& a, hipStream_t s) {
   }
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
-  // total stagger window in microseconds (SYLPH_HPIPE_STAGGER_US, 0 = off); only worth it when every CU runs several rounds
-  static const int stagger_us = getenv("SYLPH_HPIPE_STAGGER_US") ? atoi(getenv("SYLPH_HPIPE_STAGGER_US")) : 12;
-  ConvArgs b = a;
-  b.stagger = (stagger_us > 0 && grid >= 4 * 256) ? (stagger_us * 2000 / 64 + 31) / 32 : 0;  // ~2 GHz, 64 clocks per s_sleep unit, 32 steps
-  if (a.gn_coef) hipLaunchKernelGGL(conv_hpipe_kernel<true>, dim3(grid), dim3(PNT), LDS_BYTES, s, b);
-  else hipLaunchKernelGGL(conv_hpipe_kernel<false>, dim3(grid), dim3(PNT), LDS_BYTES, s, b);
+  if (a.gn_coef) hipLaunchKernelGGL(conv_hpipe_kernel<true>, dim3(grid), dim3(PNT), LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(conv_hpipe_kernel<false>, dim3(grid), dim3(PNT), LDS_BYTES, s, a);
   return (int)hipGetLastError();
 }
 

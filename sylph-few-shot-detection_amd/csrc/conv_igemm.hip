@@ -674,12 +674,7 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   a.res_lds = (res_lds_on && a.res_mode != 0 && BN == 64 && a.Cout % 64 == 0 && (a.res_ld & 7) == 0) ? 1 : 0;
   a.ss_padded_host = a.ss_padded;
   if (!ss_on || BN > 64) a.ss_padded = 0;  // the wide tiles are MFMA-bound and have no VGPRs to spare for the prefetch
-  if (BM == 256 && BN == 256) {
-    if (!conv_hpipe_ok(dt, out_f32, a)) return -8;
-    // SYLPH_CONV_HQ: 1 = the four-wave kernel (conv_hpipe4.hip: 128 x 128 wave tiles, one wave per SIMD), 0 = the eight-wave one
-    static const int hq = getenv("SYLPH_CONV_HQ") ? atoi(getenv("SYLPH_CONV_HQ")) : 0;
-    return (hq && conv_hq_ok(a)) ? launch_conv_hq(a, s) : launch_conv_hpipe(a, s);
-  }
+  if (BM == 256 && BN == 256) return conv_hpipe_ok(dt, out_f32, a) ? launch_conv_hpipe(a, s) : -8;
   if (a.KH * a.KW > 31) return -3;
   const int bk = dt == DT_BF16 ? 64 : 32;
   if (a.Cin % bk != 0) return -4;
