@@ -184,8 +184,13 @@ __global__ __launch_bounds__(1024) void decode_sort_kernel(const DecodeCfg cfg, 
 
 // suppression bits: block (cj, ci, img), 64 threads; thread t = box i = ci*64+t vs boxes of chunk cj
 __global__ __launch_bounds__(64) void nms_mask_kernel(const DecodeCfg cfg, const DecodeBuffers buf) {
-  const int cj = blockIdx.x, ci = blockIdx.y, img = blockIdx.z;
-  if (cj < ci) return;
+  // grid.x enumerates the upper triangle (ci <= cj) only: t = cj (cj + 1) / 2 + ci  (a square grid spent half of its
+  // 400 000 one-wave blocks on an immediate return: the launch was dispatch bound)
+  const int tri = blockIdx.x, img = blockIdx.z;
+  int cj = (int)((sqrtf(8.f * (float)tri + 1.f) - 1.f) * 0.5f);
+  while ((cj + 1) * (cj + 2) / 2 <= tri) ++cj;
+  while (cj * (cj + 1) / 2 > tri) --cj;
+  const int ci = tri - cj * (cj + 1) / 2;
   unsigned n = buf.pool_count[img];
   if (n > (unsigned)cfg.pool_cap) n = cfg.pool_cap;
   if ((unsigned)ci * 64u >= n || (unsigned)cj * 64u >= n) return;
@@ -328,7 +333,7 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   hipLaunchKernelGGL(decode_sort_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * cfg.pool_cap, s, cfg,
                      segs_dev, pred, pred_ld, buf);
   if (cfg.nms_thresh > 0.f) {
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw_bound, nw_bound, B), dim3(64), 0, s, cfg, buf);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw_bound * (nw_bound + 1) / 2, 1, B), dim3(64), 0, s, cfg, buf);
   }
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, s, cfg, buf, img_out_dev, out_boxes, out_scores,
                      out_classes, out_levels, out_locations, out_cand, out_counts);
