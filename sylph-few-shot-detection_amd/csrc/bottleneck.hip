@@ -284,17 +284,24 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
         const int my = (int)(((unsigned)m * inv_pw) >> 16);
         hrow[i] = t1 + (my * HW2 + (m - my * PW)) * TP + 16 * lh;
       }
-      auto p2_ptr = [&](int k, int i) {  // k-step k = tap * 4 + ks
-        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
-        return reinterpret_cast<const bf16x8*>(hrow[i] + (kh * HW2 + kw) * TP + ks * 32);
-      };
+      // Fragment ring, D2 - 1 k-steps ahead of the MFMAs.  The reads are inline asm with COUNTED waits: the next patch's halo is
+      // in flight (LDS-DMA) during this phase, and while one is pending hipcc treats the LGKM counter as out of order and turns
+      // every wait for a compiler-visible ds_read into lgkmcnt(0) -- i.e. it would wait for the reads just issued as well.
       constexpr int D2 = 4;
       bf16x8 af[D2][2];
+      auto p2_read = [&](int k) {  // k-step k = tap * 4 + ks: both row tiles
+        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-      for (int k = 0; k < D2 - 1; ++k)
+        for (int i = 0; i < 2; ++i) {
+          const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(hrow[i] + (kh * HW2 + kw) * TP);
+          if (ks == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(af[k % D2][i]) : "v"(ad));
+          else if (ks == 1) asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(af[k % D2][i]) : "v"(ad));
+          else if (ks == 2) asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(af[k % D2][i]) : "v"(ad));
+          else asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(af[k % D2][i]) : "v"(ad));
+        }
+      };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[k][i] = *p2_ptr(k, i);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D2 - 1), 0);
+      for (int k = 0; k < D2 - 1; ++k) p2_read(k);
 #ifdef BK_NOP2
       constexpr int K2 = 8;
 #else
@@ -302,10 +309,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 #endif
 #pragma unroll
       for (int k = 0; k < K2; ++k) {
-        if (k + D2 - 1 < 36) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) af[(k + D2 - 1) % D2][i] = *p2_ptr(k + D2 - 1, i);
-        }
+        if (k + D2 - 1 < 36) p2_read(k + D2 - 1);
+        // reads issued after those of k-step k: two per k-step still ahead
+        const int ahead = (k + D2 - 1 < 36 ? D2 - 1 : 35 - k) * 2;
+        if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
@@ -575,30 +585,43 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
         const int my = (int)(((unsigned)m * inv_pw) >> 16);
         hrow[i] = t1 + (my * HW2 + (m - my * PW)) * TP + 16 * lh;
       }
-      auto p2_ptr = [&](int k, int i) {
-        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
-        return reinterpret_cast<const bf16x8*>(hrow[i] + (kh * HW2 + kw) * TP + ks * 32);
-      };
+      // Fragment ring, D2 - 1 k-steps ahead of the MFMAs.  The reads are inline asm with COUNTED waits: the next patch's halo is
+      // in flight (LDS-DMA) during this phase, and while one is pending hipcc treats the LGKM counter as out of order and turns
+      // every wait for a compiler-visible ds_read into lgkmcnt(0) -- i.e. it would wait for the reads just issued as well.
       constexpr int D2 = 4;
       bf16x8 af[D2][2];
+      auto p2_read = [&](int k) {  // k-step k = tap * 4 + ks: both row tiles
+        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-      for (int k = 0; k < D2 - 1; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[k][i] = *p2_ptr(k, i);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (D2 - 1), 0);
-#pragma unroll
-      for (int k = 0; k < 36; ++k) {
-        if (k + D2 - 1 < 36) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) af[(k + D2 - 1) % D2][i] = *p2_ptr(k + D2 - 1, i);
+        for (int i = 0; i < 2; ++i) {
+          const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(hrow[i] + (kh * HW2 + kw) * TP);
+          if (ks == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(af[k % D2][i]) : "v"(ad));
+          else if (ks == 1) asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(af[k % D2][i]) : "v"(ad));
+          else if (ks == 2) asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(af[k % D2][i]) : "v"(ad));
+          else asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(af[k % D2][i]) : "v"(ad));
         }
+      };
+#pragma unroll
+      for (int k = 0; k < D2 - 1; ++k) p2_read(k);
+#ifdef BK_NOP2
+      constexpr int K2 = 8;
+#else
+      constexpr int K2 = 36;
+#endif
+#pragma unroll
+      for (int k = 0; k < K2; ++k) {
+        if (k + D2 - 1 < 36) p2_read(k + D2 - 1);
+        // reads issued after those of k-step k: two per k-step still ahead
+        const int ahead = (k + D2 - 1 < 36 ? D2 - 1 : 35 - k) * 2;
+        if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
           else BK_MFMA(acc2[i], W2f[k], af[k % D2][i]);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       }
       BK_MFMA_DRAIN2(acc2[0], acc2[1]);
       BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
