@@ -31,4 +31,4 @@ def run(nstreams, B, iters=8):
     print(f"streams={nstreams} B/stream={B}: {nstreams * B * iters / dt:8.1f} img/s (no decode)", flush=True)
     del engs
 
-run(1, 32); run(2, 16); run(2, 32); run(4, 8); run(1, 64)
+run(1, 64); run(2, 32); run(2, 64); run(3, 64); run(1, 64)
