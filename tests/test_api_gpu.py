@@ -359,3 +359,30 @@ def test_base_detector_inference_run_type_none(sd):
         base(batch, class_code={"cls_conv": w.cuda(), "cls_bias": b.cuda()}, run_type="meta_learn_test_instance")
     with pytest.raises(NotImplementedError):
         epi(batch)  # episodic models refuse run_type=None like the reference
+
+
+def test_repeated_steps_are_bit_identical(sd):
+    """Race check of the hand-synchronised kernels (counted vmcnt / lgkmcnt waits, raw barriers, LDS-DMA double buffers): the same
+    bf16 batch through preprocess -> backbone -> head -> decode must give bit-identical pyramids, head outputs and detections
+    every time (every reduction runs in a fixed order).  tools/soak_determinism.py is the long version."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.engine import Engine
+    _, cfg = _cfg()
+    eng = Engine(cfg, dtype="bf16")
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    w = (torch.randn(5, 256, 1, 1, generator=g) * 0.05).cuda()
+    b = torch.full((5,), -2.0).cuda()
+    imgs = [im.cuda() for im in W.synthetic_images(3, 352, 480, seed=31)]
+    ref = None
+    for it in range(6):
+        eng.preprocess(imgs); eng.backbone(); eng.head(w, b)
+        lo, rg, ct, _ = eng.export_head()
+        dets = eng.decode()
+        cur = [t.clone() for t in eng.export_pyramid()] + [t.clone() for t in lo + rg + ct] + \
+              [d["pred_boxes"].clone() for d in dets] + [d["scores"].clone() for d in dets]
+        if ref is None:
+            ref = cur
+            continue
+        for k, (x, y) in enumerate(zip(ref, cur)):
+            assert x.shape == y.shape and torch.equal(x, y), f"iteration {it}: tensor {k} differs"
