@@ -88,7 +88,13 @@ def config_from_cfg(cfg) -> SylphConfig:
         raise NotImplementedError("CODE_GENERATOR.ROI_BOX.POOLER_TYPE must be ROIAlignV2")
     sc.cg_meta_bias = int(bool(cg.get("META_BIAS", False)))
     sc.cond_use_bias = int(bool(cg.USE_BIAS))
-    if str(cg.NAME) == "ROIEncoder":
+    cg_name = str(cg.NAME)
+    if cg_name not in ("CodeGenerator", "ROIEncoder"):
+        # a plugged-in component (modeling.CODE_GENERATOR_REGISTRY) names the in-library generator it drives
+        from .modeling import CODE_GENERATOR_REGISTRY
+        comp = CODE_GENERATOR_REGISTRY.get(cg_name) if cg_name in CODE_GENERATOR_REGISTRY else None
+        cg_name = getattr(comp, "engine_generator", None) or cg_name
+    if cg_name == "ROIEncoder":
         # sylph/modeling/code_generator/roi_encoder.py:206-281 (dims of the LVIS ROI-Encoder yaml)
         sc.cg_type = 1
         tk, te, hd = cg.TOKENIZER, cg.TRANSFORMER_ENCODER, cg.HEAD
@@ -102,7 +108,7 @@ def config_from_cfg(cfg) -> SylphConfig:
         sc.enc_layers, sc.head_num_fc, sc.head_fc_dim = int(te.LAYERS), int(hd.NUM_FC), int(hd.FC_DIM)
         sc.cond_use_bias = 1  # CondConvBlock always passes the bias (head_utils.py:140-162)
         return sc
-    if str(cg.NAME) != "CodeGenerator":
+    if cg_name != "CodeGenerator":
         raise NotImplementedError(f"{cg.NAME} is not implemented")
     tl = list(cg.TOWER_LAYERS)
     for layer in tl:

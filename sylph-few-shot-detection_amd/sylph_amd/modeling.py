@@ -4,10 +4,12 @@
 
 keeps the reference's dispatch, argument meaning and error behaviour
 (sylph/modeling/meta_arch/meta_one_stage_detector.py:415-455) while every tensor op runs in
-libsylph_hip (one C-ABI call per stage, see sylph_amd/engine.py).  The registries keep the yaml
-names resolvable (MODEL.META_ARCHITECTURE "MetaOneStageDetector", MODEL.BACKBONE.NAME
+libsylph_hip (one C-ABI call per stage, see sylph_amd/engine.py).  The registries resolve the yaml
+names (MODEL.META_ARCHITECTURE "MetaOneStageDetector", MODEL.BACKBONE.NAME
 "build_fcos_resnet_fpn_backbone", MODEL.PROPOSAL_GENERATOR.NAME "MetaFCOS",
-MODEL.META_LEARN.CODE_GENERATOR.NAME "CodeGenerator"; sylph/modeling/code_generator/build.py:18-39).
+MODEL.META_LEARN.CODE_GENERATOR.NAME "CodeGenerator" / "ROIEncoder"; sylph/modeling/code_generator/build.py:18-39) to
+components the meta-architecture builds, binds to its HIP context and calls where the reference calls the nn.Modules:
+another implementation registered under another name plugs in the same way.
 """
 import logging
 from typing import Any, Dict, List, Optional
@@ -52,33 +54,100 @@ PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
 CODE_GENERATOR_REGISTRY = Registry("CODE_GENERATOR")
 
 
+class HipComponent:
+    """A registry entry of this package is a real (if thin) component: the meta-architecture builds it from the yaml name, binds it
+    to its HIP context and CALLS it where the reference calls the corresponding nn.Module -- so another implementation registered
+    under another name (MODEL.BACKBONE.NAME / PROPOSAL_GENERATOR.NAME / CODE_GENERATOR.NAME) is picked up the same way.  The
+    tensors stay inside the context (libsylph_hip works on the "current batch"): a component receives host-side arguments and
+    returns host-visible results."""
+
+    engine: Optional[Engine] = None
+
+    def bind(self, engine: Engine):
+        self.engine = engine
+        return self
+
+
+class FCOSResNetFPNBackbone(HipComponent):
+    """convert_batched_inputs_to_image_list + self.backbone(images.tensor) (meta_one_stage_detector.py:174-181,273): normalise,
+    pad to size_divisibility, ResNet-FPN + P6/P7.  The pyramid stays in the context as the current batch."""
+
+    size_divisibility = 32
+
+    def __init__(self, cfg, input_shape=None):
+        if list(cfg.MODEL.FPN.IN_FEATURES) != ["res3", "res4", "res5"]:
+            raise NotImplementedError("FPN.IN_FEATURES must be [res3, res4, res5]")
+        if int(cfg.MODEL.FCOS.TOP_LEVELS) != 2:
+            raise NotImplementedError("MODEL.FCOS.TOP_LEVELS must be 2 (P6, P7 from p5)")
+        if str(cfg.MODEL.FPN.get("NORM", "")) != "":
+            raise NotImplementedError("MODEL.FPN.NORM is not supported")
+        self.depth = int(cfg.MODEL.RESNETS.DEPTH)
+
+    def __call__(self, images: Optional[List[torch.Tensor]] = None, images_u8: Optional[List[torch.Tensor]] = None,
+                 resize_hw=None, rgb_input: bool = False):
+        """(3,H,W) float BGR images, or uint8 HWC originals + their ResizeShortestEdge targets (fused input pipeline).
+        Returns the per-image (h, w) the network saw (ImageList.image_sizes)."""
+        eng = self.engine
+        if images_u8 is not None:
+            sizes = [(int(s[0]), int(s[1])) for s in resize_hw]
+            eng.preprocess_u8(images_u8, sizes, rgb_input=rgb_input)
+        else:
+            eng.preprocess(images)
+            sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        eng.backbone()
+        return sizes
+
+
 @BACKBONE_REGISTRY.register()
 def build_fcos_resnet_fpn_backbone(cfg, input_shape=None):
-    """The backbone lives inside the HIP context; this entry validates the config it implies."""
-    if list(cfg.MODEL.FPN.IN_FEATURES) != ["res3", "res4", "res5"]:
-        raise NotImplementedError("FPN.IN_FEATURES must be [res3, res4, res5]")
-    if int(cfg.MODEL.FCOS.TOP_LEVELS) != 2:
-        raise NotImplementedError("MODEL.FCOS.TOP_LEVELS must be 2 (P6, P7 from p5)")
-    if str(cfg.MODEL.FPN.get("NORM", "")) != "":
-        raise NotImplementedError("MODEL.FPN.NORM is not supported")
-    return {"name": "build_fcos_resnet_fpn_backbone", "depth": int(cfg.MODEL.RESNETS.DEPTH), "size_divisibility": 32}
+    """adet backbone/fpn.py build_fcos_resnet_fpn_backbone as named by the yamls."""
+    return FCOSResNetFPNBackbone(cfg, input_shape)
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
-def MetaFCOS(cfg, input_shape=None):
-    return {"name": "MetaFCOS"}
+class MetaFCOS(HipComponent):
+    """MetaFCOS.forward at inference (meta_fcos/fcos.py:140-260): towers + class-conditional classifier on the current pyramid,
+    predict_proposals, NMS, detector_postprocess to the requested output sizes."""
+
+    def __init__(self, cfg, input_shape=None):
+        pass
+
+    def __call__(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor], out_sizes):
+        self.engine.head(cls_conv, cls_bias)
+        return self.engine.decode(out_sizes)
 
 
 @CODE_GENERATOR_REGISTRY.register()
-def CodeGenerator(cfg, feature_channels=256, feature_levels=5, strides=None):
-    assert feature_channels == 256, "Each level must have the same channel!"
-    return {"name": "CodeGenerator"}
+class CodeGenerator(HipComponent):
+    """CodeGeneratorHead: forward_roi_align on the current support pyramid (code_generator.py:924-1002) and, with cls_norm=True,
+    forward_normalize_code over a list of codes (:832-897)."""
+
+    eval_shot = None
+    engine_generator = "CodeGenerator"  # which in-library generator (sylph_config.cg_type) this component drives
+
+    def __init__(self, cfg, feature_channels=256, feature_levels=5, strides=None):
+        assert feature_channels == 256, "Each level must have the same channel!"
+
+    def __call__(self, boxes: Optional[torch.Tensor] = None, cls_norm: bool = False, class_codes=None, weight_norm=None):
+        if cls_norm:
+            return self.engine.normalize_codes(class_codes, weight_norm)
+        code = self.engine.codegen(boxes)
+        return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
 
 
 @CODE_GENERATOR_REGISTRY.register()
-def ROIEncoder(cfg, feature_channels=256, feature_levels=5, strides=None):
-    assert feature_channels == 256, "Each level must have the same channel!"
-    return {"name": "ROIEncoder", "eval_shot": int(cfg.MODEL.META_LEARN.EVAL_SHOT)}
+class ROIEncoder(HipComponent):
+    """ROIEncoder.forward at inference (roi_encoder.py:146-204): one class of EVAL_SHOT support boxes -> its code."""
+
+    engine_generator = "ROIEncoder"
+
+    def __init__(self, cfg, feature_channels=256, feature_levels=5, strides=None):
+        assert feature_channels == 256, "Each level must have the same channel!"
+        self.eval_shot = int(cfg.MODEL.META_LEARN.EVAL_SHOT)
+
+    def __call__(self, boxes: torch.Tensor):  # no cls_norm / class_codes keywords, like the reference
+        code = self.engine.codegen(boxes)
+        return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1)}
 
 
 def build_code_generator(cfg, feature_channels, feature_levels, strides):
@@ -113,6 +182,9 @@ class MetaOneStageDetector(nn.Module):
             device_index = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
         dtype = dtype or str(cfg.MODEL.get("COMPUTE_DTYPE", "bf16"))
         self.engine = Engine(cfg, dtype=dtype, device=device_index)
+        for comp in (self.backbone, self.proposal_generator, self.code_generator):
+            if hasattr(comp, "bind"):
+                comp.bind(self.engine)
         self.register_buffer("pixel_mean", torch.tensor(list(cfg.MODEL.PIXEL_MEAN), dtype=torch.float32,
                                                         device=self.engine.device).view(-1, 1, 1))
         self.register_buffer("pixel_std", torch.tensor(list(cfg.MODEL.PIXEL_STD), dtype=torch.float32,
@@ -176,24 +248,19 @@ class MetaOneStageDetector(nn.Module):
                 import numpy as np
                 gt = gt[np.random.choice(range(len(gt)), 1)]
             boxes.append(gt.reshape(1, 4))
-        eng = self.engine
-        if eng.is_roi_encoder:
+        num_shots = getattr(self.code_generator, "eval_shot", None)
+        if num_shots:
             # roi_encoder.py:156-166: num_shots = EVAL_SHOT in eval, batch = total / num_shots (one class here)
-            num_shots = self.code_generator["eval_shot"]
             assert len(records) % num_shots == 0, f"{len(records)} % {num_shots}"
             assert len(records) // num_shots == 1, "one class per call at inference"
-        eng.preprocess([rec["image"] for rec in records])
-        eng.backbone()
-        code = eng.codegen(torch.cat(boxes, dim=0))
-        if eng.is_roi_encoder:
-            return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1)}
-        return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
+        self.backbone(images=[rec["image"] for rec in records])
+        return self.code_generator(torch.cat(boxes, dim=0))
 
     def normalize_class_code(self, codes: List[Dict]):
         """code_generator.py:877-897 via meta_one_stage_detector.py:256-259 (mutates the list)."""
         assert self.episodic_learning
         assert not self.training
-        if self.engine.is_roi_encoder:
+        if isinstance(self.code_generator, ROIEncoder):
             # the reference fails the same way: ROIEncoder.forward() takes no cls_norm/class_codes
             # (meta_one_stage_detector.py:259 -> roi_encoder.py:146)
             raise TypeError("ROIEncoder.forward() got an unexpected keyword argument 'cls_norm'")
@@ -212,7 +279,7 @@ class MetaOneStageDetector(nn.Module):
                 wns.append(cc["cls_weight_norm"].reshape(-1).float())
         assert len(wns) in (0, len(rows)), "cls_weight_norm must be present for all classes or none"
         packed = torch.stack(rows).to(self.device).contiguous()
-        out = self.engine.normalize_codes(packed, torch.cat(wns) if wns else None)
+        out = self.code_generator(cls_norm=True, class_codes=packed, weight_norm=torch.cat(wns) if wns else None)
         for i, code in enumerate(codes):
             code["class_code"]["cls_conv"] = out[i, :256].reshape(1, 256, 1, 1)
             code["class_code"]["cls_bias"] = out[i, 256:257].reshape(1)
@@ -248,21 +315,15 @@ class MetaOneStageDetector(nn.Module):
         w, b = class_codes["cls_conv"], class_codes.get("cls_bias")
         assert w.dim() == 4, f"Weight has dimension: {w.dim()}"
         assert w.size(1) == 256
-        eng = self.engine
         if all("image_u8" in x for x in batched_inputs):
             # fused input pipeline: the original uint8 HWC image + its ResizeShortestEdge target; resize,
             # BGR conversion, normalisation and padding run in one HIP kernel (sylph_preprocess_u8)
-            sizes = [(int(x["resize_hw"][0]), int(x["resize_hw"][1])) for x in batched_inputs]
-            eng.preprocess_u8([x["image_u8"] for x in batched_inputs], sizes,
-                              rgb_input=str(batched_inputs[0].get("input_format", "BGR")) == "RGB")
+            sizes = self.backbone(images_u8=[x["image_u8"] for x in batched_inputs], resize_hw=[x["resize_hw"] for x in batched_inputs],
+                                  rgb_input=str(batched_inputs[0].get("input_format", "BGR")) == "RGB")
         else:
-            images = [x["image"] for x in batched_inputs]
-            eng.preprocess(images)
-            sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
-        eng.backbone()
-        eng.head(w, b)
+            sizes = self.backbone(images=[x["image"] for x in batched_inputs])
         out_sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
-        dets = eng.decode(out_sizes)
+        dets = self.proposal_generator(w, b, out_sizes)
         results = []
         for d, osz in zip(dets, out_sizes):
             r = Instances(osz)

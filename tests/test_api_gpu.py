@@ -386,3 +386,47 @@ def test_repeated_steps_are_bit_identical(sd):
             continue
         for k, (x, y) in enumerate(zip(ref, cur)):
             assert x.shape == y.shape and torch.equal(x, y), f"iteration {it}: tensor {k} differs"
+
+
+def test_registry_hosts_a_different_component(sd):
+    """The registries are real plugin points (sylph/modeling/code_generator/build.py:18-39): a code generator registered under
+    another name is built from the yaml key, bound to the model's HIP context and called by forward_class_code."""
+    from sylph_amd import modeling as M
+    from sylph_amd import synthetic as W
+    from sylph_amd.structures import Boxes, Instances
+    calls = []
+
+    @M.CODE_GENERATOR_REGISTRY.register()
+    class HalvedCodeGenerator(M.CodeGenerator):
+        def __call__(self, boxes=None, **kw):
+            out = super().__call__(boxes, **kw)
+            if isinstance(out, dict):
+                calls.append(int(boxes.shape[0]))
+                out["cls_conv"] = out["cls_conv"] * 0.5
+            return out
+
+    runner, cfg = _cfg()
+    cfg.MODEL.META_LEARN.CODE_GENERATOR.NAME = "HalvedCodeGenerator"
+    m = runner.build_model(cfg, dtype="f32")
+    assert isinstance(m.code_generator, HalvedCodeGenerator) and m.code_generator.engine is m.engine
+    m.load_state_dict(sd)
+    m.eval()
+    cfg2 = cfg.clone()
+    cfg2.MODEL.META_LEARN.CODE_GENERATOR.NAME = "CodeGenerator"
+    ref = runner.build_model(cfg2, dtype="f32")
+    ref.load_state_dict(sd)
+    ref.eval()
+    imgs = W.synthetic_images(2, 96, 128, seed=41)
+    sup = []
+    for im in imgs:
+        inst = Instances((96, 128))
+        inst.gt_boxes = Boxes(torch.tensor([[10.0, 12.0, 70.0, 80.0]]))
+        inst.gt_classes = torch.zeros(1, dtype=torch.long)
+        sup.append({"image": im, "instances": inst})
+    item = [{"support_set": sup, "support_set_target": torch.tensor(0), "class_name": "x"}]
+    a = m(item, run_type="meta_learn_test_support")
+    b = ref(item, run_type="meta_learn_test_support")
+    assert calls == [2]
+    assert torch.allclose(a["cls_conv"], b["cls_conv"] * 0.5, rtol=0, atol=0) and torch.equal(a["cls_bias"], b["cls_bias"])
+    with pytest.raises(KeyError):
+        M.CODE_GENERATOR_REGISTRY.get("NoSuchGenerator")
