@@ -5,7 +5,6 @@ iterations excluded, "s / img", "s / class code")."""
 import logging
 import os
 import time
-from collections import defaultdict
 from contextlib import ExitStack, contextmanager
 from typing import Any, Dict, List
 
@@ -29,34 +28,36 @@ def inference_context(model: nn.Module):
 
 
 def format_class_codes_shared(class_codes: List[Dict[str, Any]], device) -> Dict[str, torch.Tensor]:
-    """meta_learn_evaluation.py:71-103: order by support_set_target, concatenate, flatten cls_bias."""
-    num_classes = len(class_codes)
-    if num_classes == 0:
+    """The per-class records of loop A as one tensor per code field, row c = the class whose support_set_target is c
+    (semantics of meta_learn_evaluation.py:71-103: fields other than "snnl", cls_bias flattened to (n,); an empty list is
+    returned as it is; a class id nobody delivered fails in torch.cat like the reference's None slot does)."""
+    n = len(class_codes)
+    if n == 0:
         return class_codes
-    outs = defaultdict(list)
-    for k in class_codes[0]["class_code"].keys():
-        outs[k] = [None for _ in range(num_classes)]
-    for code in class_codes:
-        for dtype, value in code["class_code"].items():
-            if dtype == "snnl":
-                continue
-            outs[dtype][int(code["support_set_target"])] = value
-    final = {}
-    for key, value in outs.items():
-        final[key] = torch.cat([v.to(device) for v in value], dim=0)
-        if key == "cls_bias":
-            final[key] = final[key].view(final[key].numel())
-    return final
+    fields = [f for f in class_codes[0]["class_code"] if f != "snnl"]
+    by_target = {int(rec["support_set_target"]): rec["class_code"] for rec in class_codes}
+    packed = {}
+    for f in fields:
+        rows = [by_target[c][f].to(device) if c in by_target and f in by_target[c] else None for c in range(n)]
+        t = torch.cat(rows, dim=0)
+        packed[f] = t.reshape(-1) if f == "cls_bias" else t
+    if "snnl" in class_codes[0]["class_code"]:  # the reference keeps the key with its initial None slots and fails on it in cat
+        raise TypeError("expected Tensor as element 0 in argument 0, but got NoneType")
+    return packed
 
 
 def inference_normalization(model, codes: List[Dict[str, Any]]):
-    """meta_learn_evaluation.py:105-116."""
+    """meta_learn_evaluation.py:105-116: the run_type "meta_learn_normalize_code" call under eval mode and no_grad."""
     logger.info(f"Start normalizing class codes on {get_world_size()} devices")
-    with ExitStack() as stack:
-        if isinstance(model, nn.Module):
-            stack.enter_context(inference_context(model))
-        stack.enter_context(torch.no_grad())
-        return model(batched_inputs=None, class_code=codes, run_type="meta_learn_normalize_code")
+    was_training = isinstance(model, nn.Module) and model.training
+    if isinstance(model, nn.Module):
+        model.eval()
+    try:
+        with torch.no_grad():
+            return model(batched_inputs=None, class_code=codes, run_type="meta_learn_normalize_code")
+    finally:
+        if was_training:
+            model.train(True)
 
 
 def _log_totals(kind: str, unit: str, total_time: float, compute_time: float, n: int, devices: int):
