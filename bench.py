@@ -83,8 +83,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # SYLPH_BENCH_BACKEND=gloo + SYLPH_BENCH_ONE_DEVICE=1: N ranks on ONE GPU, to exercise the multi-rank control flow of this script
+        # (shards, the code gather, the barrier / max-over-ranks timing) on a single-GPU box; the real run is one rank per GPU on RCCL
+        if os.environ.get("SYLPH_BENCH_ONE_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SYLPH_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
