@@ -177,6 +177,29 @@ int sylph_group_norm(sylph_ctx* ctx, const float* x_nchw_dev, int B, int H, int 
 int sylph_stem_maxpool(sylph_ctx* ctx, const float* x_nchw_dev, int B, int H, int W, const float* w_host,
                        const float* scale_host, const float* shift_host, float* stem_out_nchw_dev, float* pool_out_nchw_dev);
 
+/* Parity taps (test boundary; no reference counterpart -- the reference's modules are called one by one from Python, so its
+ * tests can look at any intermediate; these entries give the parity tests the same view of the fused HIP graph).
+ * sylph_set_debug_taps(1) before the first head call of a batch shape: every FCOS tower layer keeps its stored conv output in
+ * its own buffer (same kernels and launches, other destination) instead of the two ping-pong buffers.
+ * sylph_export_stage: output of ResNet stage `stage` (2..5 = res2..res5) of the last sylph_backbone_fpn as
+ * (B, 256 << (stage - 2), h, w) fp32 NCHW (detectron2 ResNet.forward outputs; call site meta_one_stage_detector.py:181,273).
+ * sylph_export_tower: conv output of layer `layer` of the cls (tower 0) / bbox (tower 1) tower on FPN level `level`
+ * (sylph/modeling/meta_fcos/fcos.py:72-122,625-628) as (B,256,h_l,w_l) fp32 NCHW -- the value stored BEFORE GroupNorm when
+ * the layer's GroupNorm is applied by its consumer -- and (coef_dev != NULL) that GroupNorm's per-(image, channel)
+ * coefficients (a, b) with y = relu(a * x + b), as (B,256,2) fp32. */
+int sylph_set_debug_taps(sylph_ctx* ctx, int on);
+int sylph_export_stage(sylph_ctx* ctx, int stage, float* out_nchw_dev);
+int sylph_export_tower(sylph_ctx* ctx, int tower, int layer, int level, float* y_nchw_dev, float* coef_dev);
+
+/* Kernel parity entry: ONE detectron2 BottleneckBlock (1x1 -> 3x3 -> 1x1, FrozenBN folded to scale/shift, identity or
+ * projection shortcut, ReLU) through the same launches sylph_backbone_fpn uses for such a block (fused kernels included).
+ * x (B,Cin,H,W) fp32 NCHW device; w_host[4] = conv1 (mid,Cin,1,1), conv2 (mid,mid,3,3), conv3 (cout,mid,1,1), shortcut
+ * (cout,Cin,1,1) or NULL (identity block); scale_host / shift_host[4]: per-output-channel FrozenBN scale and shift of the
+ * same four convs (host).  y (B,cout,Ho,Wo) fp32 NCHW device.  (call site meta_one_stage_detector.py:181,273) */
+int sylph_bottleneck(sylph_ctx* ctx, const float* x_nchw_dev, int B, int Cin, int H, int W, int stride, int mid, int cout,
+                     const float* const* w_host, const float* const* scale_host, const float* const* shift_host,
+                     float* y_nchw_dev);
+
 /* Bytes of device memory currently held by the context (weights + workspace). */
 int64_t sylph_device_bytes(sylph_ctx* ctx);
 

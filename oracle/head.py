@@ -57,7 +57,8 @@ def cond_conv_block(feature, weight, bias=None, scales: Optional[List[float]] = 
 
 def fcos_head(features: List[torch.Tensor], sd: Dict[str, torch.Tensor], class_codes: Dict[str, torch.Tensor],
               num_cls_convs: int = 4, num_box_convs: int = 4, use_scale: bool = True,
-              use_bias: bool = True, cond_block: bool = False, prefix: str = HEAD_PREFIX):
+              use_bias: bool = True, cond_block: bool = False, prefix: str = HEAD_PREFIX,
+              cond_scales: Optional[List[float]] = None):
     """fcos.py:582-667 with support_set_per_class_code given.  Returns per-level lists
     (logits (B,N,h,w), reg (B,4,h,w) = relu(scale_l * bbox_pred), ctrness (B,1,h,w), iou (B,1,h,w))."""
     w = class_codes["cls_conv"]
@@ -67,7 +68,7 @@ def fcos_head(features: List[torch.Tensor], sd: Dict[str, torch.Tensor], class_c
         cls_t = tower(feat, sd, f"{prefix}.cls_tower", num_cls_convs)
         box_t = tower(feat, sd, f"{prefix}.bbox_tower", num_box_convs)
         if cond_block:
-            logit = cond_conv_block(cls_t, w, b)
+            logit = cond_conv_block(cls_t, w, b, scales=cond_scales)  # Scale parameters of the checkpoint (head_utils.py:131-136)
         else:
             logit = cond_conv_basic(cls_t, w, b, padding=0, use_bias=use_bias)
         reg = F.conv2d(box_t, sd[f"{prefix}.bbox_pred.weight"], sd[f"{prefix}.bbox_pred.bias"], padding=1)

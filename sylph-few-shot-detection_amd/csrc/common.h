@@ -56,7 +56,14 @@ struct ConvArgs {
   int tap_dy;                 // input rows advanced per kernel-row tap (1; stem: rows per K-slice)
   const float2* gn_coef;      // conv_hpipe.hip: fused GroupNorm(+ReLU) of the INPUT: per (segment, input channel) (a, b),
   int gn_relu;                //   x <- relu?(a * x + b) applied to the landed halo in LDS; row stride of gn_coef = in_ld
+  void* trash;                // conv_pw.hip: >= 4 KiB scratch where lanes without a valid output row put their (fixed number of) stores
+  const struct PwDesc* pw_desc;  // conv_pw.hip: one 64-byte descriptor per M tile (read through the scalar cache)
+  const float* pw_table;      // conv_pw.hip: [n_ntiles][scale BN | shift BN] fp32
+  int pw_rot_mask;            // set by launch_conv_pw
 };
+
+// conv_pw.hip tile descriptor (two s_load_dwordx8): geometry of the tile's segment + the tile's first row
+struct PwDesc { int row0, seg_rows, out_W, out_row0, in_row0, in_W, in2_row0, in2_W, res_row0, res_W, pad[6]; };
 
 // fused identity bottleneck (bottleneck.hip): x, y [pos][256] bf16; w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16
 // (the conv_igemm weight layouts); FrozenBN scale / shift per conv (fp32)
@@ -130,5 +137,12 @@ int launch_hpipe_pack_weights(const void* w_igemm, void* w_hpipe, int Cout, int 
 int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s);   // bottleneck.hip: identity block, persistent, weights in registers
 int launch_bottleneck64p(const BottleneckArgs& a, hipStream_t s);  // first block of res2: x [pos][64], w3 = [256][128] packed [W3 | Wsc], y = relu(acc + b3)
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
+// conv_pw.hip: persistent pipelined pointwise (1x1) conv, bf16; a.wt = the layer's stage-image weights (launch_pw_pack_weights),
+// a.tiles = BM-row tiles, a.pw_desc / a.pw_table as below; (BM, BN) from conv_pw_tile (false: not eligible)
+bool conv_pw_tile(int cout, int k_total, bool has_res, int* BM, int* BN);
+bool conv_pw_ok(DType dt, bool out_f32, const ConvArgs& a);
+int launch_conv_pw(const ConvArgs& a, int BM, int BN, hipStream_t s);
+int launch_pw_pack_weights(const void* w_igemm, void* w_pw, int Cout, int K, int BN, hipStream_t s);
+int launch_pw_pack_table(const float* scale, const float* shift, float* out, int Cout, int BN, hipStream_t s);
 
 }  // namespace sylph

@@ -163,6 +163,8 @@ struct sylph_ctx {
   std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
   std::map<std::pair<int, int>, std::shared_ptr<struct PilCoeffs>> pil_cache;  // (in size, out size) -> resampling tables
   std::map<const void*, void*> hp_weights;  // conv_hpipe.hip re-packed copies of 3x3 weights, keyed by the igemm-layout pointer
+  std::map<const void*, std::pair<void*, float*>> pw_weights;  // conv_pw.hip stage-image copies of 1x1 weights + scale/shift tables, keyed by the igemm-layout pointer
+  void* pw_trash = nullptr;                 // conv_pw.hip trash slots (4 KiB)
   Plan* cur = nullptr;
   void* zeros = nullptr;  // 256 B of zeros (conv out-of-image taps)
   // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
@@ -175,6 +177,7 @@ struct sylph_ctx {
   // plans are evicted least-recently-used first once their count or their bytes exceed the budget, so a stream of
   // distinct padded shapes (real COCO / LVIS episodes) cannot grow HBM without bound.
   Plan* alloc_owner = nullptr;
+  bool debug_taps = false;  // sylph_set_debug_taps: tower layers keep their outputs in separate buffers (parity tests)
   uint64_t use_clock = 0;
   size_t max_plans = 32;
   int64_t plan_byte_budget = 0;  // 0 = set from the device size at context creation
@@ -202,6 +205,13 @@ struct Plan {
   // backbone
   void *x0 = nullptr, *stem_out = nullptr, *pool_out = nullptr;
   void* F = nullptr;  // pyramid [B*Ltot][256]
+  void* bk_trash = nullptr;  // trash slots of the fused bottleneck kernels
+  // parity taps (sylph_export_stage / sylph_export_tower): where the stage outputs res2..res5 and, with debug taps on, every
+  // tower layer's stored conv output and GroupNorm coefficient table live
+  const void* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_h[4] = {0, 0, 0, 0}, stage_w[4] = {0, 0, 0, 0};
+  std::vector<const void*> tap_out[2];      // [cls | bbox][layer]: conv output [rows][256] (pre-GroupNorm when tap_coef is set)
+  std::vector<const float2*> tap_coef[2];   // [cls | bbox][layer]: (a, b) per (segment, channel), nullptr if applied in place
   std::vector<OpFn> backbone_ops, head_ops, support_ops;
   bool backbone_built = false, head_built = false, support_built = false;
   ImageDesc* img_desc_dev = nullptr;
@@ -377,6 +387,25 @@ static int make_conv_bias(sylph_ctx* c, const std::vector<std::string>& names, C
   }
   RET(pack_conv(c, ws, L));
   RET(upload_vec(c, &L->shift, bias, L->Cout_pad));
+  return 0;
+}
+
+// conv3 + projection shortcut as one pointwise layer over K = [conv3 inputs | shortcut inputs]: the two FrozenBN scales
+// are folded into the weights in fp32 (before the dtype cast), the shifts are summed; no epilogue scale.
+static int make_c3sc(sylph_ctx* c, const HostTensor& w3, const float* s3, const float* h3, const HostTensor& ws, const float* ss,
+                     const float* hs, ConvLayer* L) {
+  const int co = (int)w3.shape[0], k3 = (int)w3.shape[1], ks = (int)ws.shape[1];
+  HostTensor hc;
+  hc.shape = {co, k3 + ks, 1, 1};
+  hc.data.resize((size_t)co * (k3 + ks));
+  std::vector<float> shift(co);
+  for (int i = 0; i < co; ++i) {
+    for (int k = 0; k < k3; ++k) hc.data[(size_t)i * (k3 + ks) + k] = w3.data[(size_t)i * k3 + k] * s3[i];
+    for (int k = 0; k < ks; ++k) hc.data[(size_t)i * (k3 + ks) + k3 + k] = ws.data[(size_t)i * ks + k] * ss[i];
+    shift[i] = h3[i] + hs[i];
+  }
+  RET(pack_conv(c, {&hc}, L));
+  RET(upload_vec(c, &L->shift, shift, L->Cout_pad));
   return 0;
 }
 
@@ -609,6 +638,28 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
     const long patch_rows = patch_count(segs, 128, 184, 2) * 128;
     if (halo_on != 2 && patch_rows * 10 > rows * 15) halo = false;
   }
+  // pointwise bf16 layers: persistent pipelined kernel (conv_pw.hip) when the launch has at least one tile per block slot
+  static const int pw_on = getenv("SYLPH_CONV_PW") ? atoi(getenv("SYLPH_CONV_PW")) : 1;
+  bool pw = false;
+  int pw_bm = 0, pw_bn = 0;
+  if (pw_on && !hpipe && !halo && c->dt == DT_BF16 && !o.out_f32 && L.KH == 1 && L.KW == 1 && o.pad == 0 && !o.stem && o.group_cout == 0 &&
+      o.mul_nch == 0 && !o.want_gn && !o.gn_coef && o.cout_override < 0 && L.Cout == L.Cout_pad &&
+      (o.relu_nch == 0 || o.relu_nch >= L.Cout) && L.Cin % 32 == 0 && L.Cin >= 128 && (!o.in2 || o.Cin2 % 32 == 0) &&
+      conv_pw_tile(L.Cout, L.Cin, o.res_mode != 0, &pw_bm, &pw_bn)) {
+    const int bn = pw_bn, bm = pw_bm;
+    const long tiles = ((rows + bm - 1) / bm) * (L.Cout / bn);
+    // 32-bit byte offsets into the activation buffers
+    long in_rows = 0, in2_rows = 0, res_rows = 0;
+    for (auto& sg : segs) {
+      in_rows = std::max(in_rows, (long)sg.in_row0 + (long)sg.in_H * sg.in_W);
+      in2_rows = std::max(in2_rows, (long)sg.in2_row0 + (long)sg.out_H * o.stride2 * sg.in2_W);
+      res_rows = std::max(res_rows, (long)sg.res_row0 + (long)sg.res_H * sg.res_W);
+    }
+    const bool fits = in_rows * in_ld * 2 < (1L << 32) && (!o.in2 || in2_rows * o.in2_ld * 2 < (1L << 32)) &&
+                      (!o.res || res_rows * o.res_ld * 2 < (1L << 32));
+    pw = fits && (pw_on == 2 || tiles >= 256);
+    if (pw) { BM = bm; BN = bn; }
+  }
   Geom g;
   if (hpipe) RET(make_geom_patch(c, segs, 128, 256, 4, true, &g));
   else if (halo) RET(make_geom_patch(c, segs, 128, 184, 2, false, &g));
@@ -628,6 +679,43 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
       it = c->hp_weights.emplace(L.w, wp).first;
     }
     a.wt = it->second;
+  }
+  if (pw) {  // stage-image weight layout + scale/shift table of conv_pw.hip, packed once per layer; one descriptor per M tile
+    auto it = c->pw_weights.find(L.w);
+    if (it == c->pw_weights.end()) {
+      void* wp = nullptr;
+      float* tb = nullptr;
+      OwnerScope ctx_owned(c, nullptr);
+      RET(c->dalloc(&wp, (size_t)L.Cout * L.Cin * 2));
+      RET(c->dalloc((void**)&tb, (size_t)2 * L.Cout * sizeof(float)));
+      KCHK(launch_pw_pack_weights(L.w, wp, L.Cout, L.Cin, BN, c->stream), "pw_pack_weights");
+      KCHK(launch_pw_pack_table(L.scale, L.shift, tb, L.Cout, BN, c->stream), "pw_pack_table");
+      HIPCHK(hipStreamSynchronize(c->stream));
+      it = c->pw_weights.emplace(L.w, std::make_pair(wp, tb)).first;
+    }
+    a.wt = it->second.first;
+    a.pw_table = it->second.second;
+    if (!c->pw_trash) {
+      OwnerScope ctx_owned(c, nullptr);
+      RET(c->dalloc(&c->pw_trash, 4096));
+    }
+    a.trash = c->pw_trash;
+    std::vector<PwDesc> pd;
+    for (size_t sgi = 0; sgi < segs.size(); ++sgi) {
+      const SegDesc& sg = segs[sgi];
+      const int nrows = sg.out_H * sg.out_W;
+      for (int r = 0; r < nrows; r += BM) {
+        PwDesc d;
+        memset(&d, 0, sizeof(d));
+        d.row0 = r; d.seg_rows = nrows; d.out_W = sg.out_W; d.out_row0 = sg.out_row0; d.in_row0 = sg.in_row0; d.in_W = sg.in_W;
+        d.in2_row0 = sg.in2_row0; d.in2_W = o.in2 ? sg.in2_W : sg.out_W; d.res_row0 = sg.res_row0; d.res_W = sg.res_W;
+        pd.push_back(d);
+      }
+    }
+    if ((int)pd.size() != g.n_mtiles) return fail("internal: conv_pw descriptor count");
+    void* pdd = nullptr;
+    RET(upload(c, &pdd, pd.data(), pd.size() * sizeof(PwDesc)));
+    a.pw_desc = (const PwDesc*)pdd;
   }
   a.scale = L.scale; a.shift = L.shift; a.zeros = c->zeros;
   a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = hpipe ? (g.n_mtiles + 1) / 2 : g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;
@@ -651,6 +739,11 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   const DType dt = c->dt;
   const bool of32 = o.out_f32;
   const double flops = o.flops >= 0.0 ? o.flops : 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
+  if (pw) {
+    if (!conv_pw_ok(dt, of32, a)) return fail("internal: conv_pw selected for a layer it cannot run");
+    ops.push_back([a, BM, BN, c, flops](hipStream_t s) { return timed_op(c, flops, s, [=](hipStream_t st) { return launch_conv_pw(a, BM, BN, st); }); });
+    return 0;
+  }
   ops.push_back([a, BM, BN, dt, of32, c, flops](hipStream_t s) { return timed_conv(c, dt, of32, a, BM, BN, flops, s); });
   return 0;
 }
@@ -752,6 +845,76 @@ static int ensure_pyramid(sylph_ctx* c, Plan* P) {
   return 0;
 }
 
+// One ResNet bottleneck block (detectron2 BottleneckBlock: 1x1 -> 3x3 -> 1x1, FrozenBN folded, residual / projection shortcut)
+// appended to `ops`: X [B][Hin*Win][Cin] -> Y [B][Ho*Wo][cout].  t1 / t2 / sc are scratch activations of the stage.
+// Shared by build_backbone and the single-block parity entry sylph_bottleneck, so both run the same kernels.
+struct BkScratch { void *t1, *t2, *sc; void** trash; };
+static int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block& blk, int B, const void* X, int Cin, int Hin, int Win,
+                          int stride, int mid, int cout, void* Y, const BkScratch& scr) {
+  const DType dt = c->dt;
+  const int s1 = c->cfg.stride_in_1x1 ? stride : 1, s3 = c->cfg.stride_in_1x1 ? 1 : stride;
+  const int H1 = (Hin - 1) / s1 + 1, W1 = (Win - 1) / s1 + 1;
+  const int Ho = (Hin - 1) / stride + 1, Wo = (Win - 1) / stride + 1;
+  void *t1 = scr.t1, *t2 = scr.t2, *sc = scr.sc;
+  // res2 identity blocks (C 256, mid 64, stride 1, no projection), bf16: ONE fused kernel (bottleneck.hip): the two
+  // 64-channel intermediates and the second read of x never reach HBM (2 048 -> 1 024 B per position)
+  static const int fuse_bn = getenv("SYLPH_FUSE_BOTTLENECK") ? atoi(getenv("SYLPH_FUSE_BOTTLENECK")) : 1;
+  const bool fuse_id = fuse_bn && dt == DT_BF16 && !blk.has_sc && stride == 1 && mid == 64 && Cin == 256 && cout == 256 &&
+                       blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3.Cout_pad == 256;
+  // first block of res2 (64 -> 64 -> 64 -> 256, projection folded into conv3's GEMM, stride 1): one fused kernel too
+  const bool fuse_pr = fuse_bn && dt == DT_BF16 && blk.fused_sc && stride == 1 && mid == 64 && Cin == 64 && cout == 256 &&
+                       blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3sc.Cout_pad == 256 && blk.c3sc.Cin == 128 && !blk.c3sc.scale;
+  if ((fuse_id || fuse_pr) && (size_t)B * Hin * Win * 512 < ((size_t)1 << 32)) {  // the kernels address x with 32-bit byte offsets
+    BottleneckArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.x = X; ba.y = Y;
+    ba.w1 = (const __bf16*)blk.c1.w; ba.w2 = (const __bf16*)blk.c2.w; ba.w3 = (const __bf16*)(fuse_id ? blk.c3.w : blk.c3sc.w);
+    ba.s1 = blk.c1.scale; ba.b1 = blk.c1.shift; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
+    ba.s3 = fuse_id ? blk.c3.scale : nullptr; ba.b3 = fuse_id ? blk.c3.shift : blk.c3sc.shift;
+    ba.zeros = c->zeros;
+    if (!*scr.trash) RET(c->dalloc(scr.trash, (size_t)1024 * 256 * 128));  // per-thread trash slots (grid <= CU count <= 1024)
+    ba.trash = *scr.trash;
+    std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
+    std::vector<BkTile> bt;
+    int ph, pw;
+    pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
+    for (size_t si2 = 0; si2 < sg.size(); ++si2)
+      for (int yy = 0; yy < Hin; yy += ph)
+        for (int xx = 0; xx < Win; xx += pw)
+          bt.push_back(BkTile{sg[si2].in_row0, Hin, Win, (yy << 16) | xx, ph, pw, (65536u + pw - 1) / pw, (65536u + pw + 2 - 1) / (pw + 2)});
+    void* btd = nullptr;
+    RET(upload(c, &btd, bt.data(), bt.size() * sizeof(BkTile)));
+    ba.bk = (const BkTile*)btd;
+    ba.n_tiles = (int)bt.size();
+    const double fl = 2.0 * (double)B * Hin * Win * (fuse_id ? (256.0 * 64 + 64.0 * 576 + 64.0 * 256) : (64.0 * 64 + 64.0 * 576 + 128.0 * 256));
+    if (fuse_id) ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64(ba, st); }); });
+    else ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
+    return 0;
+  }
+  ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
+  RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
+  ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
+  RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
+  if (blk.fused_sc) {
+    // conv3 + projection shortcut as ONE pointwise GEMM over K = [t2 | X(strided)]: the shortcut
+    // tensor is never written to / re-read from HBM
+    std::vector<SegDesc> sg = image_segs(B, Ho, Wo, Ho, Wo);
+    for (int b = 0; b < B; ++b) { sg[b].in2_row0 = b * Hin * Win; sg[b].in2_W = Win; }
+    ConvOpts o3; o3.relu_nch = 1 << 30; o3.in2 = X; o3.in2_ld = Cin; o3.Cin2 = Cin; o3.stride2 = stride;
+    RET(add_conv(c, ops, blk.c3sc, t2, mid, Y, cout, sg, o3));
+  } else {
+    const void* resid = X;
+    if (blk.has_sc) {
+      ConvOpts os; os.stride = stride;
+      RET(add_conv(c, ops, blk.sc, X, Cin, sc, cout, image_segs(B, Hin, Win, Ho, Wo), os));
+      resid = sc;
+    }
+    ConvOpts o3; o3.relu_nch = 1 << 30; o3.res = resid; o3.res_ld = cout; o3.res_mode = 1;
+    RET(add_conv(c, ops, blk.c3, t2, mid, Y, cout, image_segs(B, Ho, Wo, Ho, Wo), o3));
+  }
+  return 0;
+}
+
 static int build_backbone(sylph_ctx* c, Plan* P) {
   if (P->backbone_built) return 0;
   if (!c->has_backbone) return fail("backbone weights were not loaded");
@@ -812,100 +975,15 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
     RET(c->dalloc(&Yb, (size_t)B * Hs * Ws * cout * e));
     auto& blocks = c->stages[si];
     void* Y = nullptr;
-    void* bk_trash = nullptr;
+    BkScratch scr{t1, t2, sc, &P->bk_trash};
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
-      const auto& blk = blocks[bi];
       const int stride = bi == 0 ? first_stride : 1;
-      const int s1 = c->cfg.stride_in_1x1 ? stride : 1, s3 = c->cfg.stride_in_1x1 ? 1 : stride;
-      const int H1 = (Hin - 1) / s1 + 1, W1 = (Win - 1) / s1 + 1;
-      const int Ho = (Hin - 1) / stride + 1, Wo = (Win - 1) / stride + 1;
       Y = (Y == Ya) ? Yb : Ya;
-      // res2 identity blocks (C 256, mid 64, stride 1, no projection), bf16: ONE fused kernel (bottleneck.hip): the two
-      // 64-channel intermediates and the second read of x never reach HBM (2 048 -> 1 024 B per position)
-      static const int fuse_bn = getenv("SYLPH_FUSE_BOTTLENECK") ? atoi(getenv("SYLPH_FUSE_BOTTLENECK")) : 1;
-      if (fuse_bn && dt == DT_BF16 && !blk.has_sc && stride == 1 && mid == 64 && Cin == 256 && cout == 256 &&
-          blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3.Cout_pad == 256 &&
-          (size_t)B * Hin * Win * 512 < ((size_t)1 << 32)) {  // the kernel addresses x with 32-bit byte offsets
-        BottleneckArgs ba;
-        memset(&ba, 0, sizeof(ba));
-        ba.x = X; ba.y = Y;
-        ba.w1 = (const __bf16*)blk.c1.w; ba.w2 = (const __bf16*)blk.c2.w; ba.w3 = (const __bf16*)blk.c3.w;
-        ba.s1 = blk.c1.scale; ba.b1 = blk.c1.shift; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
-        ba.s3 = blk.c3.scale; ba.b3 = blk.c3.shift;
-        ba.zeros = c->zeros;
-        if (!bk_trash) RET(c->dalloc(&bk_trash, (size_t)1024 * 256 * 128));  // per-thread trash slots (grid <= CU count <= 1024)
-        ba.trash = bk_trash;
-        std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
-        std::vector<BkTile> bt;
-        int ph, pw;
-        pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
-        for (size_t si2 = 0; si2 < sg.size(); ++si2)
-          for (int yy = 0; yy < Hin; yy += ph)
-            for (int xx = 0; xx < Win; xx += pw)
-              bt.push_back(BkTile{sg[si2].in_row0, Hin, Win, (yy << 16) | xx, ph, pw, (65536u + pw - 1) / pw, (65536u + pw + 2 - 1) / (pw + 2)});
-        void* btd = nullptr;
-        RET(upload(c, &btd, bt.data(), bt.size() * sizeof(BkTile)));
-        ba.bk = (const BkTile*)btd;
-        ba.n_tiles = (int)bt.size();
-        const double fl = 2.0 * (double)B * Hin * Win * (256.0 * 64 + 64.0 * 576 + 64.0 * 256);
-        ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64(ba, st); }); });
-        X = Y;
-        continue;
-      }
-      // first block of res2 (64 -> 64 -> 64 -> 256, projection folded into conv3's GEMM, stride 1): one fused kernel too
-      if (fuse_bn && dt == DT_BF16 && blk.fused_sc && stride == 1 && mid == 64 && Cin == 64 && cout == 256 &&
-          blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3sc.Cout_pad == 256 && blk.c3sc.Cin == 128 && !blk.c3sc.scale &&
-          (size_t)B * Hin * Win * 512 < ((size_t)1 << 32)) {
-        BottleneckArgs ba;
-        memset(&ba, 0, sizeof(ba));
-        ba.x = X; ba.y = Y;
-        ba.w1 = (const __bf16*)blk.c1.w; ba.w2 = (const __bf16*)blk.c2.w; ba.w3 = (const __bf16*)blk.c3sc.w;
-        ba.s1 = blk.c1.scale; ba.b1 = blk.c1.shift; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
-        ba.s3 = nullptr; ba.b3 = blk.c3sc.shift;
-        ba.zeros = c->zeros;
-        if (!bk_trash) RET(c->dalloc(&bk_trash, (size_t)1024 * 256 * 128));
-        ba.trash = bk_trash;
-        std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
-        std::vector<BkTile> bt;
-        int ph, pw;
-        pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
-        for (size_t si2 = 0; si2 < sg.size(); ++si2)
-          for (int yy = 0; yy < Hin; yy += ph)
-            for (int xx = 0; xx < Win; xx += pw)
-              bt.push_back(BkTile{sg[si2].in_row0, Hin, Win, (yy << 16) | xx, ph, pw, (65536u + pw - 1) / pw, (65536u + pw + 2 - 1) / (pw + 2)});
-        void* btd = nullptr;
-        RET(upload(c, &btd, bt.data(), bt.size() * sizeof(BkTile)));
-        ba.bk = (const BkTile*)btd;
-        ba.n_tiles = (int)bt.size();
-        const double fl = 2.0 * (double)B * Hin * Win * (64.0 * 64 + 64.0 * 576 + 128.0 * 256);
-        ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
-        X = Y; Cin = cout;
-        continue;
-      }
-      ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
-      RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
-      ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
-      RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
-      if (blk.fused_sc) {
-        // conv3 + projection shortcut as ONE pointwise GEMM over K = [t2 | X(strided)]: the shortcut
-        // tensor is never written to / re-read from HBM
-        std::vector<SegDesc> sg = image_segs(B, Ho, Wo, Ho, Wo);
-        for (int b = 0; b < B; ++b) { sg[b].in2_row0 = b * Hin * Win; sg[b].in2_W = Win; }
-        ConvOpts o3; o3.relu_nch = 1 << 30; o3.in2 = X; o3.in2_ld = Cin; o3.Cin2 = Cin; o3.stride2 = stride;
-        RET(add_conv(c, ops, blk.c3sc, t2, mid, Y, cout, sg, o3));
-      } else {
-        const void* resid = X;
-        if (blk.has_sc) {
-          ConvOpts os; os.stride = stride;
-          RET(add_conv(c, ops, blk.sc, X, Cin, sc, cout, image_segs(B, Hin, Win, Ho, Wo), os));
-          resid = sc;
-        }
-        ConvOpts o3; o3.relu_nch = 1 << 30; o3.res = resid; o3.res_ld = cout; o3.res_mode = 1;
-        RET(add_conv(c, ops, blk.c3, t2, mid, Y, cout, image_segs(B, Ho, Wo, Ho, Wo), o3));
-      }
-      X = Y; Hin = Ho; Win = Wo; Cin = cout;
+      RET(add_bottleneck(c, ops, blocks[bi], B, X, Cin, Hin, Win, stride, mid, cout, Y, scr));
+      X = Y; Hin = (Hin - 1) / stride + 1; Win = (Win - 1) / stride + 1; Cin = cout;
     }
     stage_out[si] = X; stage_h[si] = Hin; stage_w[si] = Win;
+    P->stage_out[si] = X; P->stage_h[si] = Hin; P->stage_w[si] = Win;
   }
   // FPN (res3..res5 -> p3..p5), top-down with nearest 2x upsample fused as a residual, then P6/P7
   void* lat[3] = {nullptr, nullptr, nullptr};
@@ -1012,7 +1090,7 @@ static int build_head(sylph_ctx* c, Plan* P) {
   RET(ensure_gn_ws(c, P, nseg > P->B ? nseg : P->B, max_rows));
   const std::vector<SegDesc> segs = pyramid_segs(c, P);
   auto& ops = P->head_ops;
-  auto tower = [&](const std::vector<ConvLayer>& convs, const std::vector<GNLayer>& gns, void* b0, void* b1,
+  auto tower = [&](int which, const std::vector<ConvLayer>& convs, const std::vector<GNLayer>& gns, void* b0, void* b1,
                    void** last, const float2** coef_last, OpFn* apply_last) -> int {
     const bool defer_last = coef_last != nullptr;
     const void* in = P->F;
@@ -1034,8 +1112,11 @@ static int build_head(sylph_ctx* c, Plan* P) {
       RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1, defer ? &coef : nullptr, (is_last && defer_last) ? &apply : nullptr));
       if (is_last && defer_last) { *coef_last = coef; *apply_last = apply; }
       coef_prev = coef;
+      P->tap_out[which].push_back(out);
+      P->tap_coef[which].push_back(coef);
       in = out;
       out = (out == b0) ? b1 : b0;
+      if (c->debug_taps && !is_last) RET(c->dalloc(&out, rows * 256 * e));  // keep every layer's output (same kernels, other destination)
     }
     *last = const_cast<void*>(in);
     return 0;
@@ -1075,10 +1156,10 @@ static int build_head(sylph_ctx* c, Plan* P) {
     P->cls_coef = nullptr; P->cls_apply = nullptr;
     const bool defer = gn_logits_on && c->dt == DT_BF16;
     OpFn cls_apply;
-    RET(tower(c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat, (defer && !c->cls_tower.empty()) ? &P->cls_coef : nullptr, &cls_apply));
+    RET(tower(0, c->cls_tower, c->cls_gn, P->tA, P->tB, &cls_feat, (defer && !c->cls_tower.empty()) ? &P->cls_coef : nullptr, &cls_apply));
     P->cls_apply = cls_apply;
     box_defer = defer && c->pred_taps && !c->box_tower.empty();
-    RET(tower(c->box_tower, c->box_gn, P->tC, P->tD, &box_feat, box_defer ? &box_coef : nullptr, &box_apply));
+    RET(tower(1, c->box_tower, c->box_gn, P->tC, P->tD, &box_feat, box_defer ? &box_coef : nullptr, &box_apply));
   }
   P->cls_ld = feat_ld;
   Geom g32;  // 128-row pointwise tiles of the pyramid (class-conditional conv with N <= 32, fused GN + prediction pass)
@@ -1484,7 +1565,7 @@ int sylph_finalize_weights(sylph_ctx* c) {
         if (blk.has_sc && !(fz && atoi(fz) == 0)) {
           // fold the two FrozenBN scales into the weights, sum the shifts (fp32 before the dtype cast)
           const HostTensor *w3 = find_w(c, q + ".conv3.weight"), *ws = find_w(c, q + ".shortcut.weight");
-          const int co = (int)w3->shape[0], k3 = (int)w3->shape[1], ks = (int)ws->shape[1];
+          const int co = (int)w3->shape[0];
           std::vector<float> s3(co), h3(co), ss(co), hs(co);
           for (int i = 0; i < co; ++i) {
             const float a3 = find_w(c, q + ".conv3.norm.weight")->data[i] *
@@ -1496,17 +1577,7 @@ int sylph_finalize_weights(sylph_ctx* c) {
             ss[i] = as;
             hs[i] = find_w(c, q + ".shortcut.norm.bias")->data[i] - find_w(c, q + ".shortcut.norm.running_mean")->data[i] * as;
           }
-          HostTensor hc;
-          hc.shape = {co, k3 + ks, 1, 1};
-          hc.data.resize((size_t)co * (k3 + ks));
-          std::vector<float> shift(co);
-          for (int i = 0; i < co; ++i) {
-            for (int k = 0; k < k3; ++k) hc.data[(size_t)i * (k3 + ks) + k] = w3->data[(size_t)i * k3 + k] * s3[i];
-            for (int k = 0; k < ks; ++k) hc.data[(size_t)i * (k3 + ks) + k3 + k] = ws->data[(size_t)i * ks + k] * ss[i];
-            shift[i] = h3[i] + hs[i];
-          }
-          RET(pack_conv(c, {&hc}, &blk.c3sc));
-          RET(upload_vec(c, &blk.c3sc.shift, shift, blk.c3sc.Cout_pad));
+          RET(make_c3sc(c, *w3, s3.data(), h3.data(), *ws, ss.data(), hs.data(), &blk.c3sc));
           blk.fused_sc = true;
         }
       }
@@ -2076,6 +2147,87 @@ int sylph_conv2d(sylph_ctx* c, const float* x, int B, int C, int H, int W, const
   for (int b = 0; b < B; ++b)
     KCHK(launch_export_nchw(c->dt, yout, y + (size_t)b * Cout * Ho * Wo, Cout, Ho * Wo, b * Ho * Wo, Cout, c->stream),
          "export");
+  return 0;
+}
+
+int sylph_set_debug_taps(sylph_ctx* c, int on) {
+  c->debug_taps = on != 0;
+  return 0;
+}
+
+int sylph_export_stage(sylph_ctx* c, int stage, float* out) {
+  Plan* P = c->cur;
+  if (!P || !P->backbone_built) return fail("no backbone pass on the current batch");
+  if (stage < 2 || stage > 5 || !P->stage_out[stage - 2]) return fail("bad stage");
+  HIPCHK(hipSetDevice(c->device));
+  const int si = stage - 2, C = 256 << si, hw = P->stage_h[si] * P->stage_w[si];
+  for (int b = 0; b < P->B; ++b)
+    KCHK(launch_export_nchw(c->dt, P->stage_out[si], out + (size_t)b * C * hw, C, hw, b * hw, C, c->stream), "export stage");
+  return 0;
+}
+
+int sylph_export_tower(sylph_ctx* c, int tower, int layer, int level, float* y, float* coef) {
+  Plan* P = c->cur;
+  if (!P || !P->head_built) return fail("no head pass on the current batch");
+  if (tower < 0 || tower > 1 || layer < 0 || layer >= (int)P->tap_out[tower].size()) return fail("bad tower / layer");
+  if (level < 0 || level >= c->cfg.nlevels) return fail("bad level");
+  if (!c->debug_taps && layer + 1 != (int)P->tap_out[tower].size()) return fail("intermediate tower layers need sylph_set_debug_taps(1) before the first head call");
+  HIPCHK(hipSetDevice(c->device));
+  const int hw = P->hl[level] * P->wl[level], L = c->cfg.nlevels;
+  for (int b = 0; b < P->B; ++b) {
+    if (y) KCHK(launch_export_nchw(c->dt, P->tap_out[tower][layer], y + (size_t)b * 256 * hw, 256, hw, b * P->Ltot + P->off[level], 256, c->stream), "export tower");
+    if (coef) {
+      if (!P->tap_coef[tower][layer]) return fail("this layer's GroupNorm was applied in place (no coefficient table)");
+      HIPCHK(hipMemcpyAsync(coef + (size_t)b * 512, P->tap_coef[tower][layer] + (size_t)(b * L + level) * 256, 512 * sizeof(float),
+                            hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  return 0;
+}
+
+int sylph_bottleneck(sylph_ctx* c, const float* x, int B, int Cin, int H, int W, int stride, int mid, int cout, const float* const* w_host,
+                     const float* const* scale_host, const float* const* shift_host, float* y) {
+  HIPCHK(hipSetDevice(c->device));
+  const int bk = c->dt == DT_BF16 ? 64 : 32;
+  if (Cin % bk != 0 || mid % bk != 0) return fail("sylph_bottleneck: channel counts must be multiples of " + std::to_string(bk));
+  const bool has_sc = w_host[3] != nullptr;
+  if (!has_sc && (Cin != cout || stride != 1)) return fail("sylph_bottleneck: an identity block needs Cin == cout and stride 1");
+  sylph_ctx tmp;  // scratch allocations freed on return
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros; tmp.cfg = c->cfg;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
+  sylph_ctx::Block blk;
+  const int cins[4] = {Cin, mid, mid, Cin}, couts[4] = {mid, mid, cout, cout}, ks[4] = {1, 3, 1, 1};
+  ConvLayer* Ls[4] = {&blk.c1, &blk.c2, &blk.c3, &blk.sc};
+  HostTensor hw[4];
+  for (int i = 0; i < (has_sc ? 4 : 3); ++i) {
+    hw[i].shape = {couts[i], cins[i], ks[i], ks[i]};
+    hw[i].data.assign(w_host[i], w_host[i] + (size_t)couts[i] * cins[i] * ks[i] * ks[i]);
+    RET(pack_conv(&tmp, {&hw[i]}, Ls[i]));
+    RET(upload_vec(&tmp, &Ls[i]->scale, std::vector<float>(scale_host[i], scale_host[i] + couts[i]), Ls[i]->Cout_pad));
+    RET(upload_vec(&tmp, &Ls[i]->shift, std::vector<float>(shift_host[i], shift_host[i] + couts[i]), Ls[i]->Cout_pad));
+  }
+  blk.has_sc = has_sc;
+  const char* fz = getenv("SYLPH_FUSE_SHORTCUT");
+  if (has_sc && !(fz && atoi(fz) == 0)) {
+    RET(make_c3sc(&tmp, hw[2], scale_host[2], shift_host[2], hw[3], scale_host[3], shift_host[3], &blk.c3sc));
+    blk.fused_sc = true;
+  }
+  const size_t e = tmp.esz();
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  void *xin, *yout, *t1, *t2, *sc, *trash = nullptr;
+  RET(tmp.dalloc(&xin, (size_t)B * H * W * Cin * e));
+  RET(tmp.dalloc(&yout, (size_t)B * Ho * Wo * cout * e));
+  RET(tmp.dalloc(&t1, (size_t)B * H * W * mid * e));
+  RET(tmp.dalloc(&t2, (size_t)B * Ho * Wo * mid * e));
+  RET(tmp.dalloc(&sc, (size_t)B * Ho * Wo * cout * e));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_import_nchw(c->dt, x + (size_t)b * Cin * H * W, xin, Cin, H * W, b * H * W, Cin, c->stream), "import");
+  std::vector<OpFn> ops;
+  BkScratch scr{t1, t2, sc, &trash};
+  RET(add_bottleneck(&tmp, ops, blk, B, xin, Cin, H, W, stride, mid, cout, yout, scr));
+  RET(run_ops(c, ops, "bottleneck"));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_export_nchw(c->dt, yout, y + (size_t)b * cout * Ho * Wo, cout, Ho * Wo, b * Ho * Wo, cout, c->stream), "export");
   return 0;
 }
 

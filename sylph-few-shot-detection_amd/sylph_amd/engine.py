@@ -461,6 +461,50 @@ class Engine:
         check(self.L.sylph_stem_maxpool(self._ctx, _ptr(x), B, H, W, _ptr(wh), _ptr(sc), _ptr(sh), _ptr(so), _ptr(po)), "stem_maxpool")
         return so, po
 
+    # ---- parity taps (tests) ---------------------------------------------------------------------------
+    def set_debug_taps(self, on: bool = True):
+        """Keep every tower layer's stored output (call before the first head pass of a batch shape)."""
+        check(self.L.sylph_set_debug_taps(self._ctx, int(on)), "set_debug_taps")
+
+    def export_stage(self, stage: int) -> torch.Tensor:
+        """res<stage> output of the last backbone pass, (B, C, h, w) fp32 NCHW."""
+        self._stream()
+        B, H, W, _ = self._batch
+        h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        for _ in range(stage - 1):
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out = torch.empty(B, 256 << (stage - 2), h, w, device=self.device)
+        check(self.L.sylph_export_stage(self._ctx, stage, _ptr(out)), "export_stage")
+        return out
+
+    def export_tower(self, tower: int, layer: int, with_coef: bool = True):
+        """Per level: (conv output (B,256,h,w), GroupNorm coefficients (B,256,2) or None) of one tower layer."""
+        self._stream()
+        B, H, W, _ = self._batch
+        ys, cs = [], []
+        for l, (h, w) in enumerate(self.level_shapes(H, W)):
+            y = torch.empty(B, 256, h, w, device=self.device)
+            cf = torch.empty(B, 256, 2, device=self.device) if with_coef else None
+            check(self.L.sylph_export_tower(self._ctx, tower, layer, l, _ptr(y), _ptr(cf)), "export_tower")
+            ys.append(y); cs.append(cf)
+        return ys, cs
+
+    def bottleneck(self, x, ws, scales, shifts, stride=1):
+        """One ResNet bottleneck block through the backbone's own launches.  ws / scales / shifts: conv1, conv2, conv3,
+        shortcut (or None) weights and folded FrozenBN scale / shift."""
+        self._stream()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, Cin, H, W = x.shape
+        mid, cout = ws[0].shape[0], ws[2].shape[0]
+        n = 4 if len(ws) > 3 and ws[3] is not None else 3
+        keep = [[t.detach().cpu().float().contiguous() for t in lst[:n]] for lst in (ws, scales, shifts)]
+        arrs = [(c_void_p * 4)(*([t.data_ptr() for t in lst] + [None] * (4 - n))) for lst in keep]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(B, cout, Ho, Wo, device=self.device)
+        check(self.L.sylph_bottleneck(self._ctx, _ptr(x), B, Cin, H, W, stride, mid, cout, arrs[0], arrs[1], arrs[2], _ptr(y)),
+              "bottleneck")
+        return y
+
     def device_bytes(self) -> int:
         return int(self.L.sylph_device_bytes(self._ctx))
 

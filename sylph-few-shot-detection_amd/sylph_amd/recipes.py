@@ -49,6 +49,23 @@ RECIPES = {
         fcos={"POST_NMS_TOPK_TEST": 300, "NUM_CLS_CONVS": 4, "CLS_LOGITS_KERNEL_SIZE": 1, "NORM": "GN"},
         code_generator={"BIAS_L2_NORM": True, "USE_WEIGHT_SCALE": True, "USE_PER_CLS_SCALE": True,
                         "ROI_BOX": {"POOLER_RESOLUTION": 7, "POOLER_TYPE": "ROIAlignV2"}}),
+    # LVIS v1 with the ROIEncoder hyper-network (configs/LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml on top of
+    # Base-Meta-FCOS.yaml): transformer code generator, CondConvBlock head; run it with MetaFCOSROIEncoderRunner
+    "LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml": {
+        "MODEL": dict(copy.deepcopy(_R50_FPN_P3_P7), **{
+            "META_ARCHITECTURE": "MetaOneStageDetector",
+            "PROPOSAL_GENERATOR": {"NAME": "MetaFCOS", "OWD": False},
+            "FCOS": {"NUM_CLASSES": 1103, "POST_NMS_TOPK_TEST": 300, "NUM_CLS_CONVS": 4, "CLS_LOGITS_KERNEL_SIZE": 1, "NORM": "GN",
+                     "BOX_QUALITY": ["ctrness"]},
+            "META_LEARN": {"EPISODIC_LEARNING": True, "CLASS": 3, "SHOT": 5, "EVAL_SHOT": 10, "QUERY_SHOT": 1,
+                           "CODE_GENERATOR": {
+                               "NAME": "ROIEncoder",
+                               "ROI_BOX": {"POOLER_RESOLUTION": 7, "POOLER_TYPE": "ROIAlignV2"},
+                               "TOKENIZER": {"NUM_CONV": 2, "CONV_DIM": 256, "NORM": "GN", "NUM_FC": 2, "FC_DIM": 256},
+                               "TRANSFORMER_ENCODER": {"LAYERS": 2, "HEADS": 8, "DROPOUT": 0.1},
+                               "HEAD": {"NUM_FC": 2, "FC_DIM": 512, "OUTPUT_DIM": 256}}},
+        }),
+    },
 }
 
 

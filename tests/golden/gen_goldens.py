@@ -121,6 +121,42 @@ def gen_head_decode():
     np.savez_compressed(os.path.join(HERE, "g1_head_decode.npz"), **out)
 
 
+def gen_decode_variants():
+    """predict_proposals under the other MODEL.FCOS.BOX_QUALITY / THRESH_WITH_CTR settings
+    (sylph/modeling/meta_fcos/fcos_outputs.py:938-959) on the head outputs of g1's 5-way case: inputs are g1's
+    `n5_t50_logits*`, `reg*`, `ctr*`, `iou*` (regenerated here, asserted equal), outputs are the reference's proposals.
+    Separate file so that g1_head_decode.npz stays bit-stable."""
+    from sylph.modeling.meta_fcos.fcos import MetaFCOS
+    from ref_shim import ShapeSpec
+    cfg = make_cfg()
+    sd = W.head_state_dict(seed=1, num_classes=60)
+    shapes = {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(3, 8)}
+    model = MetaFCOS(cfg, shapes).eval()
+    load_prefixed(model, sd, "proposal_generator")
+    H, Wd, B = 128, 160, 2
+    feats = feature_pyramid(B, H, Wd, seed=11)
+    image_sizes = [(H, Wd - 7), (H - 5, Wd)]
+    g1 = np.load(os.path.join(HERE, "g1_head_decode.npz"))
+    out = {"weights_checksum": checksum(sd, "proposal_generator")}
+    with torch.no_grad():
+        codes = W.synthetic_codes(5, seed=35, scale=2.0)
+        logits, reg, ctr, iou, _, _ = model.fcos_head(feats, None, False, codes)
+        for l in range(5):
+            assert np.array_equal(logits[l].numpy(), g1[f"n5_t50_logits{l}"]) and np.array_equal(iou[l].numpy(), g1[f"iou{l}"])
+        locations = model.compute_locations(feats)
+        for bq, twc, tag in ((["iou"], False, "iou"), (["ctrness", "iou"], False, "ctriou"), (["ctrness"], True, "ctr_twc"),
+                             (["iou"], True, "iou_twc"), (["ctrness", "iou"], True, "ctriou_twc")):
+            model.fcos_outputs.box_quality = bq
+            model.fcos_outputs.thresh_with_ctr = twc
+            model.fcos_outputs.pre_nms_thresh_test = 0.05
+            props = model.fcos_outputs.predict_proposals(logits, reg, ctr, iou, locations, image_sizes, [])
+            for i, p in enumerate(props):
+                out.update(inst_to_np(p, f"{tag}_img{i}"))
+            out[f"{tag}_count"] = np.array([len(p) for p in props])
+            print("decode variant", tag, [len(p) for p in props])
+    np.savez_compressed(os.path.join(HERE, "g1b_decode_variants.npz"), **out)
+
+
 def gen_codegen():
     from sylph.modeling.code_generator.code_generator import CodeGenerator
     from ref_shim import Boxes, Instances
@@ -298,7 +334,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
-    for fn in (gen_head_decode, gen_codegen, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+    for fn in (gen_head_decode, gen_decode_variants, gen_codegen, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
         if not only or fn.__name__ in only:
             fn()
     print("done")

@@ -156,6 +156,38 @@ def test_decode_matches_reference_golden(g1, tag, thr):
         np.testing.assert_allclose(d["pred_boxes"].cpu().numpy(), ref["pred_boxes"].numpy(), atol=1e-3, rtol=1e-4)
 
 
+DECODE_VARIANTS = [("iou", ["iou"], False), ("ctriou", ["ctrness", "iou"], False), ("ctr_twc", ["ctrness"], True),
+                   ("iou_twc", ["iou"], True), ("ctriou_twc", ["ctrness", "iou"], True)]
+
+
+@pytest.mark.parametrize("tag,bq,twc", DECODE_VARIANTS)
+def test_decode_variants_match_reference_golden(g1, golden_dir, tag, bq, twc):
+    """quality_mode 1 / 2 (MODEL.FCOS.BOX_QUALITY ["iou"], ["ctrness","iou"]) and THRESH_WITH_CTR of the device decode
+    (fcos_outputs.py:938-959): the reference's own head outputs go in through sylph_import_head, the kept
+    (level, location, class) triples must be the reference's, scores / boxes within 1e-3."""
+    from oracle.decode import detector_postprocess
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g1b_decode_variants.npz"))
+    eng = _engine("f32", _cfg(**{"MODEL.FCOS.BOX_QUALITY": bq, "MODEL.FCOS.THRESH_WITH_CTR": twc}))
+    assert int(eng.sc.quality_mode) == {"iou": 1, "ctriou": 2, "ctr": 0}[tag.split("_")[0]] and int(eng.sc.thresh_with_ctr) == int(twc)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.import_head([torch.from_numpy(g1[f"n5_t50_logits{l}"]) for l in range(5)], [torch.from_numpy(g1[f"reg{l}"]) for l in range(5)],
+                    [torch.from_numpy(g1[f"ctr{l}"]) for l in range(5)], [torch.from_numpy(g1[f"iou{l}"]) for l in range(5)])
+    dets = eng.decode()
+    for i, d in enumerate(dets):
+        pre = f"{tag}_img{i}"
+        ref = {k: torch.from_numpy(g[f"{pre}_{k}"]) for k in ("pred_boxes", "scores", "pred_classes", "fpn_levels", "locations")}
+        ref = detector_postprocess(ref, sizes[i], sizes[i][0], sizes[i][1])
+        assert d["scores"].numel() == ref["scores"].numel() > 0
+        np.testing.assert_array_equal(d["pred_classes"].cpu().numpy(), ref["pred_classes"].numpy())
+        np.testing.assert_array_equal(d["fpn_levels"].cpu().numpy(), ref["fpn_levels"].numpy())
+        np.testing.assert_array_equal(d["locations"].cpu().numpy(), ref["locations"].numpy())
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
+        np.testing.assert_allclose(d["pred_boxes"].cpu().numpy(), ref["pred_boxes"].numpy(), atol=1e-3, rtol=1e-4)
+
+
 @pytest.mark.parametrize("lvis", [False, True])
 @pytest.mark.parametrize("S", [1, 2, 5])
 def test_codegen_matches_reference_golden(g3, lvis, S):

@@ -71,6 +71,30 @@ def test_decode_matches_reference(g1, head_sd, tag, thr):
         np.testing.assert_allclose(p["pred_boxes"].numpy(), g1[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
 
 
+VARIANTS = [("iou", ["iou"], False), ("ctriou", ["ctrness", "iou"], False), ("ctr_twc", ["ctrness"], True),
+            ("iou_twc", ["iou"], True), ("ctriou_twc", ["ctrness", "iou"], True)]
+
+
+@pytest.mark.parametrize("tag,bq,twc", VARIANTS)
+def test_decode_variants_match_reference(g1, golden_dir, tag, bq, twc):
+    """MODEL.FCOS.BOX_QUALITY ["iou"] / ["ctrness","iou"] and THRESH_WITH_CTR (fcos_outputs.py:938-959) on the reference's own
+    head outputs (g1's 5-way case) against the reference's proposals (g1b_decode_variants.npz)."""
+    g = _load(golden_dir, "g1b_decode_variants.npz")
+    logits = [torch.from_numpy(g1[f"n5_t50_logits{l}"]) for l in range(5)]
+    regs = [torch.from_numpy(g1[f"reg{l}"]) for l in range(5)]
+    ctrs = [torch.from_numpy(g1[f"ctr{l}"]) for l in range(5)]
+    ious = [torch.from_numpy(g1[f"iou{l}"]) for l in range(5)]
+    props = D.predict_proposals(logits, regs, ctrs, ious, box_quality=bq, thresh_with_ctr=twc)
+    for i, p in enumerate(props):
+        pre = f"{tag}_img{i}"
+        assert p["scores"].numel() == int(g[f"{tag}_count"][i])
+        np.testing.assert_array_equal(p["pred_classes"].numpy(), g[f"{pre}_pred_classes"])
+        np.testing.assert_array_equal(p["fpn_levels"].numpy(), g[f"{pre}_fpn_levels"])
+        np.testing.assert_array_equal(p["locations"].numpy(), g[f"{pre}_locations"])
+        np.testing.assert_allclose(p["scores"].numpy(), g[f"{pre}_scores"], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(p["pred_boxes"].numpy(), g[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
+
+
 @pytest.fixture(scope="module")
 def g3(golden_dir):
     return _load(golden_dir, "g3_codegen.npz")
