@@ -394,15 +394,16 @@ int launch_pw_pack_weights(const void* w, void* out, int Cout, int K, int BN, hi
   return (int)hipGetLastError();
 }
 
-// Tile shape of a pointwise layer (false: not eligible).  Most of these layers are HBM-bound: 128 x 128 tiles, 4 ring stages
-// (three phases of activations in flight per block), residual tile prefetched at the tile start.  Layers well above the
-// machine balance (K N / (K + N (1 + residual)) flop per byte, ridge ~ 200) take the 128 x 256 tile (256 x 128 when
-// Cout % 256 != 0): the operand ratio of conv_hpipe.  SYLPH_PW_TILE = 1 / 2 forces the small / large tile (tuning knob).
+// Tile shape of a pointwise layer (false: not eligible): 128 x 256 (256 x 128 when Cout % 256 != 0), 3 ring stages -- the operand
+// ratio of conv_hpipe (12 fragment reads per 16 MFMAs) and 6 LDS-DMA instructions per wave and phase.  The 128 x 128 / 4-stage
+// variant (whole residual tile prefetched at the tile start, three activation phases in flight) is kept for A/B runs
+// (SYLPH_PW_TILE=1): measured 5-25 % slower on every layer of the R-50 graph -- per 32-channel phase a wave pays one barrier,
+// one counted wait and its LDS-DMA issue slots (~100 cycles each) for only 8 MFMAs.
 bool conv_pw_tile(int cout, int k_total, bool has_res, int* BM, int* BN) {
   static const int force = getenv("SYLPH_PW_TILE") ? atoi(getenv("SYLPH_PW_TILE")) : 0;
   if (cout % 128 != 0) return false;
-  const double ai = (double)k_total * cout / ((double)k_total + (double)cout * (has_res ? 2.0 : 1.0));
-  const bool large = force == 2 || (force == 0 && ai > 250.0);
+  (void)k_total; (void)has_res;
+  const bool large = force != 1;
   if (large) { *BN = cout % 256 == 0 ? 256 : 128; *BM = 384 - *BN; }
   else { *BM = 128; *BN = 128; }
   return true;

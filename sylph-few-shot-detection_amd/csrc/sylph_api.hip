@@ -657,7 +657,12 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
     }
     const bool fits = in_rows * in_ld * 2 < (1L << 32) && (!o.in2 || in2_rows * o.in2_ld * 2 < (1L << 32)) &&
                       (!o.res || res_rows * o.res_ld * 2 < (1L << 32));
-    pw = fits && (pw_on == 2 || tiles >= 256);
+    // Where it pays (in-situ timeline at B = 64, profiles/r3_*): every pointwise layer without a same-geometry residual -- bottleneck
+    // conv1 (-13 ... -20 %), conv3 + projection as one GEMM (-14 ... -20 %), FPN laterals incl. the top-down add (-10 ... -15 %) --
+    // except the res3-shaped identity conv1 (N = 128, stride 1: already at 5 TB/s in conv_igemm).  With a residual tile to fetch the
+    // two kernels are equal (res4 / res5) or conv_igemm's five co-resident blocks win (res3, K = 128): those stay there.
+    const bool pays = o.res_mode != 1 && (L.Cout % 256 == 0 || o.stride != 1);
+    pw = fits && (pw_on == 2 || (tiles >= 256 && pays));
     if (pw) { BM = bm; BN = bn; }
   }
   Geom g;

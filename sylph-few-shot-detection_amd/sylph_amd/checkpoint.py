@@ -63,8 +63,8 @@ def convert_caffe2_names(sd: Dict[str, Any]) -> Dict[str, Any]:
         else:
             continue  # not a backbone blob
         kind = m.group(m.lastindex)
-        if kind == "bn_riv":  # running inverse std -> running_var (FrozenBN eps 1e-5), rarely present
-            v = 1.0 / (torch.as_tensor(v).float() ** 2) - 1e-5
+        # bn_riv goes to running_var UNCHANGED: detectron2's convert_basic_c2_names only renames it (c2_model_loading.py), and the
+        # reference loads checkpoints through that loader
         suffix = {"w": "weight", "b": "bias", "bn_s": "norm.weight", "bn_b": "norm.bias", "bn_rm": "norm.running_mean",
                   "bn_riv": "norm.running_var"}[kind]
         out[f"{base}.{suffix}"] = v

@@ -102,7 +102,7 @@ class CfgNode(dict):
         if BASE_KEY in cfg:
             base = cfg.pop(BASE_KEY)
             base = reroute_config_path(base)
-            if not base.startswith("/") and not base.startswith("~"):
+            if not base.startswith("/") and not base.startswith("~") and not base.startswith(SYLPH_PREFIX):
                 base = os.path.join(os.path.dirname(filename), base)
             merged = CfgNode.load_yaml_with_base(base)
             _merge_dict(cfg, merged)

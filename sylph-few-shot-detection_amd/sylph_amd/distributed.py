@@ -26,7 +26,7 @@ import torch.distributed as dist
 CODE_DIM = 256
 F_BIAS, F_ACC, F_CID, F_VALID, F_WNORM, F_HAS_WNORM, F_NAME, NAME_FLOATS = 256, 257, 258, 259, 260, 261, 264, 16
 ROW = F_NAME + NAME_FLOATS
-NAME_BYTES = 4 * NAME_FLOATS
+NAME_BYTES = 3 * NAME_FLOATS  # 3 name bytes per fp32 lane (exact integers < 2^24)
 
 
 def get_world_size() -> int:
@@ -53,13 +53,18 @@ def shard_capacity(n: int, world: int = None) -> int:
 
 
 def _name_floats(names: Optional[Sequence[Optional[str]]], n: int) -> torch.Tensor:
-    raw = np.zeros((n, NAME_BYTES), dtype=np.uint8)
+    """Class names as fp32 lanes that survive ANY fp32 hop, not only bit copies: one byte per lane would waste the block, so
+    each lane carries 3 name bytes as an integer < 2^24 (exactly representable; no NaN / denormal bit patterns)."""
+    vals = np.zeros((n, NAME_FLOATS), dtype=np.float32)
     if names is not None:
         for i, s in enumerate(names):
             if s:
-                b = str(s).encode("utf-8")[:NAME_BYTES]
-                raw[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
-    return torch.from_numpy(raw.view(np.float32).reshape(n, NAME_FLOATS))
+                b = str(s).encode("utf-8")
+                assert len(b) <= NAME_BYTES, f"class name {s!r} is longer than {NAME_BYTES} bytes"
+                pad = b + b"\0" * (3 * NAME_FLOATS - len(b))
+                arr = np.frombuffer(pad, dtype=np.uint8).reshape(NAME_FLOATS, 3).astype(np.uint32)
+                vals[i] = (arr[:, 0] | (arr[:, 1] << 8) | (arr[:, 2] << 16)).astype(np.float32)
+    return torch.from_numpy(vals)
 
 
 def pack_codes(cls_conv: torch.Tensor, cls_bias: torch.Tensor, class_ids, acc_weight=None, weight_norm=None,
@@ -84,8 +89,9 @@ def pack_codes(cls_conv: torch.Tensor, cls_bias: torch.Tensor, class_ids, acc_we
 
 
 def unpack_names(rows: torch.Tensor) -> List[str]:
-    """The 64-byte name fields of host rows -> strings (bit patterns survive the fp32 transport: copies only)."""
-    raw = rows[:, F_NAME:].contiguous().cpu().numpy().view(np.uint8).reshape(rows.shape[0], NAME_BYTES)
+    """The name lanes of host rows -> strings (3 bytes per fp32 lane, see _name_floats)."""
+    v = rows[:, F_NAME:].contiguous().cpu().numpy().round().astype(np.uint32)
+    raw = np.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], axis=2).astype(np.uint8).reshape(rows.shape[0], -1)
     return [bytes(r).split(b"\0", 1)[0].decode("utf-8", "replace") for r in raw]
 
 
@@ -121,7 +127,8 @@ def scatter_by_class_id(rows: torch.Tensor, num_classes: int) -> torch.Tensor:
     """format_class_codes_shared ordering (meta_learn_evaluation.py:71-103) without a host sync: out[c] <- the valid row
     whose class id is c; invalid rows land in a scratch slot.  out[:, F_VALID] tells which classes arrived."""
     cid = rows[:, F_CID].round().to(torch.int64)
-    idx = torch.where(rows[:, F_VALID] > 0, cid.clamp(0, num_classes - 1), torch.full_like(cid, num_classes))
+    ok = (rows[:, F_VALID] > 0) & (cid >= 0) & (cid < num_classes)  # an out-of-range id must not overwrite another class's code
+    idx = torch.where(ok, cid, torch.full_like(cid, num_classes))
     out = torch.zeros(num_classes + 1, rows.shape[1], dtype=rows.dtype, device=rows.device)
     out.index_copy_(0, idx, rows)
     return out[:num_classes]
@@ -131,6 +138,9 @@ def order_by_class_id(rows: torch.Tensor, num_classes: int, check: bool = True) 
     """scatter_by_class_id + (optionally, one host sync) the reference's completeness assertion."""
     out = scatter_by_class_id(rows, num_classes)
     if check:
+        cid = rows[:, F_CID].round()
+        bad = int(((rows[:, F_VALID] > 0) & ((cid < 0) | (cid >= num_classes))).sum().item())
+        assert bad == 0, f"{bad} class code(s) carry a class id outside [0, {num_classes})"
         got = int(out[:, F_VALID].sum().item())
         assert got == num_classes, f"Got {got} class codes for prediction, but expect to be {num_classes}."
     return out

@@ -156,6 +156,7 @@ class Engine:
         self.is_roi_encoder = int(self.sc.cg_type) == 1
         self.cond_scale = 1.0  # CondConvBlock Scale of the first chunk (ROIEncoder head), read from the checkpoint
         self.cond_scales = [1.0]  # all CondConvBlock Scales (one per 256-channel chunk of the class code)
+        self._cond_scales_loaded = False  # did the checkpoint carry cond_cls_logits.scales.*?
         self._batch = None  # (B, H, W, [(h,w)...])
         self._ncls = 0
         self._keep = []  # tensors that must outlive queued kernels
@@ -185,6 +186,7 @@ class Engine:
                 while len(self.cond_scales) <= i:
                     self.cond_scales.append(1.0)
                 self.cond_scales[i] = float(v.reshape(-1)[0])
+                self._cond_scales_loaded = True
                 if i == 0:
                     self.cond_scale = self.cond_scales[0]
             t = v.detach().to("cpu", torch.float32).contiguous()
@@ -268,20 +270,28 @@ class Engine:
             out.append(t)
         return out
 
-    def head(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor]):
+    def head(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor], raw: bool = False):
+        """raw=True: plain `conv(cls_tower, w, b)` even on a ROIEncoder model -- the checkpoint's own cls_logits run without the
+        CondConvBlock Scale (forward_base_train, fcos.py:544-570,592-593)."""
         self._stream()
         assert cls_conv.dim() == 4, f"Weight has dimension: {cls_conv.dim()}"
         assert cls_conv.size(2) == 1 and cls_conv.size(3) == 1
         k = cls_conv.size(1) // 256
         assert cls_conv.size(1) == 256 * k and k >= 1, f"weight has wrong shape, {tuple(cls_conv.shape)}"
-        assert k == 1 or self.is_roi_encoder, "feature.size(1) != weight.size(1)"  # CondConvBasic (head_utils.py:69)
+        assert k == 1 or (self.is_roi_encoder and not raw), "feature.size(1) != weight.size(1)"  # CondConvBasic (head_utils.py:69)
         w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256 * k)
         b = cls_bias.to(self.device, torch.float32).reshape(-1).contiguous() if cls_bias is not None else None
-        if self.is_roi_encoder:
+        if self.is_roi_encoder and not raw:
             # CondConvBlock (head_utils.py:140-162): sum over 256-channel chunks of scale_i * conv(feature, w_i, bias); the
             # reference indexes the Scale of chunk i+1 with i (head_utils.py:157-161).  conv is linear in (w, bias), so
             # the block is ONE class-conditional conv with w_eff = sum_i s_i' w_i and bias_eff = (sum_i s_i') bias.
-            sc = list(self.cond_scales) if len(self.cond_scales) >= max(k - 1, 1) else [1.0 / k] * k
+            if not self._cond_scales_loaded:
+                sc = [1.0 / k] * k  # Scale init of the reference (head_utils.py:131-136): no learned value in the checkpoint
+            else:
+                if len(self.cond_scales) < max(k - 1, 1):
+                    raise ValueError(f"the checkpoint has {len(self.cond_scales)} cond_cls_logits scales; a {256 * k}-channel class "
+                                     f"code needs {max(k - 1, 1)}")
+                sc = list(self.cond_scales)
             per_chunk = [sc[0]] + [sc[i] for i in range(k - 1)]
             w = sum(s * w[:, 256 * i:256 * (i + 1)] for i, s in enumerate(per_chunk))
             b = b * float(sum(per_chunk)) if b is not None else None

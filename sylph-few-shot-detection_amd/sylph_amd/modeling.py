@@ -112,8 +112,8 @@ class MetaFCOS(HipComponent):
     def __init__(self, cfg, input_shape=None):
         pass
 
-    def __call__(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor], out_sizes):
-        self.engine.head(cls_conv, cls_bias)
+    def __call__(self, cls_conv: torch.Tensor, cls_bias: Optional[torch.Tensor], out_sizes, raw: bool = False):
+        self.engine.head(cls_conv, cls_bias, raw=raw)
         return self.engine.decode(out_sizes)
 
 
@@ -299,6 +299,7 @@ class MetaOneStageDetector(nn.Module):
 
     def _detect(self, batched_inputs: List[Dict[str, Any]], class_codes):
         assert not self.training, "Not for training"
+        pretrained = class_codes is None
         if class_codes is None:
             # MetaFCOSHead.forward with support_set_per_class_code=None -> forward_base_train (fcos.py:543-578):
             # logits = self.cls_logits(cls_tower), the pretrained base-class classifier.  A 1x1 cls_logits conv (the
@@ -323,7 +324,8 @@ class MetaOneStageDetector(nn.Module):
         else:
             sizes = self.backbone(images=[x["image"] for x in batched_inputs])
         out_sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
-        dets = self.proposal_generator(w, b, out_sizes)
+        # the checkpoint's own cls_logits are a plain conv: no CondConvBlock Scale on a ROIEncoder model
+        dets = self.proposal_generator(w, b, out_sizes, raw=True) if pretrained else self.proposal_generator(w, b, out_sizes)
         results = []
         for d, osz in zip(dets, out_sizes):
             r = Instances(osz)

@@ -66,7 +66,7 @@ def _codes_from_rows(rows: torch.Tensor, keep_acc: bool, extras: Dict[int, Dict[
         if keep_acc:
             cc["acc_weight"] = float(r[D.F_ACC])
         rec = dict(extras.get(cid, {})) if extras else {}
-        rec.update({"support_set_target": cid, "class_name": name if name else rec.get("class_name"), "class_code": cc})
+        rec.update({"support_set_target": cid, "class_name": rec.get("class_name") or name, "class_code": cc})
         out.append(rec)
     return out
 
@@ -128,7 +128,9 @@ class MetaFCOSRunner:
                 dist.all_reduce(cap, op=dist.ReduceOp.MAX)
                 capacity = max(int(cap.item()), 1)
             rows = D.gather_packed_codes(local, capacity)
-            has_acc = reduce or any("acc_weight" in c["class_code"] for c in sub_class_codes)
+            # decided on the GATHERED rows, i.e. identically on every rank (a rank with an empty shard has no local evidence)
+            valid = rows[:, D.F_VALID] > 0
+            has_acc = reduce or bool(((rows[:, D.F_ACC] != 1.0) & valid).any().item())
             out_codes = _codes_from_rows(rows, keep_acc=has_acc)
         else:
             out_codes = sub_class_codes

@@ -190,7 +190,7 @@ def _worker(rank, world, port, golden_dir, out):
         gathered = MetaFCOSRunner._gather_class_code(mine)
         reduced = MetaFCOSRunner._gather_class_code(mine, reduce=True)
         # dense-block gather with an empty rank
-        local = (D.pack_codes(torch.randn(3, 256), torch.randn(3), [4, 5, 6], names=["cat", "d\u00f6g", "x" * 80])
+        local = (D.pack_codes(torch.randn(3, 256), torch.randn(3), [4, 5, 6], names=["cat", "d\u00f6g", "x" * 48])
                  if rank == 1 else torch.zeros(0, D.ROW))
         rows = D.gather_packed_codes(local, capacity=4)  # ONE all_gather_into_tensor of equal-size blocks
         if rank == 0:
@@ -219,9 +219,17 @@ def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
     rows = res["rows"]
     assert rows.shape == (8, D.ROW) and rows[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1, 1, 0]
     assert rows[4:7, D.F_CID].tolist() == [4.0, 5.0, 6.0]
-    assert D.unpack_names(rows[4:7]) == ["cat", "d\u00f6g", "x" * 64]
+    assert D.unpack_names(rows[4:7]) == ["cat", "d\u00f6g", "x" * 48]
+    assert torch.isfinite(rows).all() and (rows[:, D.F_NAME:] == rows[:, D.F_NAME:].round()).all()  # names travel as exact integers
+    with pytest.raises(AssertionError):
+        D.pack_codes(torch.randn(1, 256), torch.randn(1), [0], names=["y" * 49])  # no silent truncation
     by_id = D.scatter_by_class_id(rows, 8)
     assert by_id[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1, 1, 0] and torch.equal(by_id[5], rows[5])
+    # a class id outside [0, num_classes) must not land on another class's slot
+    small = D.scatter_by_class_id(rows, 6)
+    assert small[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1] and torch.equal(small[5], rows[5])
+    with pytest.raises(AssertionError):
+        D.order_by_class_id(rows, 6)
 
 
 def test_detections_to_coco_rows_batches_one_copy():
