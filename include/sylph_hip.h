@@ -141,6 +141,12 @@ int sylph_decode_nms(sylph_ctx* ctx, const int* out_heights, const int* out_widt
  * S = EVAL_SHOT shots of one class): cls_conv[256] ++ cls_bias[1] (prior already added, no
  * normalisation step exists for this variant). */
 int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
+/* The same for SEVERAL classes in one batch (support-path throughput: C4 runs 866 classes x 5 shots through the R-101 backbone):
+ * the current batch holds n_classes x shots support images, class k = images [k * shots, (k + 1) * shots); boxes_dev
+ * (n_classes * shots, 4); codes_out_dev (n_classes, 257).  The reference computes one class per call
+ * (meta_one_stage_detector.py:229-254); per class the arithmetic here is the same (ROIAlign, tower, GroupNorm and the shot mean
+ * are per image / per class), only the launches are shared.  CodeGenerator only (ROIEncoder: shots must equal the batch). */
+int sylph_codegen_classes(sylph_ctx* ctx, const float* boxes_dev, int shots, float* codes_out_dev);
 
 /* Boundary/test entry: the ROIPooler call of the code generator alone (code_generator.py:341-348,928-930: box ->
  * level assignment -> ROIAlignV2 aligned, adaptive sampling, 7x7).  The current batch holds S images, boxes_dev (S,4)
@@ -215,6 +221,10 @@ int sylph_profile_enable(sylph_ctx* ctx, int on);
 int sylph_bench_conv(sylph_ctx* ctx, int B, int H, int W, int Cin, int Cout, int K, int stride, int pad, int has_res,
                      int relu, int with_gn, int iters, float* ms_out, double* flops_out);
 int sylph_profile_read(sylph_ctx* ctx, double* conv_ms, double* conv_flops, int64_t* conv_launches);
+/* The same records grouped by kernel (consumes them like sylph_profile_read): names_out = max_kernels x 64 bytes (NUL-terminated
+ * kernel names in first-launch order), ms / flops / launches per kernel; *n_out kernels were written. */
+int sylph_profile_read_kernels(sylph_ctx* ctx, int max_kernels, char* names_out, double* ms_out, double* flops_out,
+                               int64_t* launches_out, int* n_out);
 
 #ifdef __cplusplus
 }

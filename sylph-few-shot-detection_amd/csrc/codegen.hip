@@ -83,11 +83,15 @@ int launch_roi_align(DType dt, const void* feats, int ld, const LevelDesc* lv_de
   return (int)hipGetLastError();
 }
 
-// conv_out [S*npos][conv_ld] fp32, bias_out [S*npos][bias_ld] fp32 (channel 0) -> code_out[C+1]
+// conv_out [ncls*S*npos][conv_ld] fp32, bias_out [ncls*S*npos][bias_ld] fp32 (channel 0) -> code_out[ncls][C+1]; one block per class
+// (its S consecutive support images: the arithmetic of a class does not depend on how many classes share the batch)
 __global__ __launch_bounds__(256) void codegen_tail_kernel(const float* __restrict__ conv_out, int conv_ld,
                                                            const float* __restrict__ bias_out, int bias_ld, int S,
                                                            int npos, int C, int bias_l2_norm, int has_bias,
                                                            float* __restrict__ code_out) {
+  conv_out += (size_t)blockIdx.x * S * npos * conv_ld;
+  if (has_bias) bias_out += (size_t)blockIdx.x * S * npos * bias_ld;
+  code_out += (size_t)blockIdx.x * (C + 1);
   const float wshot = 1.0f / (float)S;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float code = 0.f;
@@ -119,10 +123,10 @@ __global__ __launch_bounds__(256) void codegen_tail_kernel(const float* __restri
   }
 }
 
-int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int S, int npos, int C,
+int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int ncls, int S, int npos, int C,
                         int bias_l2_norm, int has_bias, float* code_out, hipStream_t s) {
-  if (npos > 64) return -1;
-  hipLaunchKernelGGL(codegen_tail_kernel, dim3(1), dim3(256), 0, s, conv_out, conv_ld, bias_out, bias_ld, S, npos, C,
+  if (npos > 64 || ncls < 1) return -1;
+  hipLaunchKernelGGL(codegen_tail_kernel, dim3(ncls), dim3(256), 0, s, conv_out, conv_ld, bias_out, bias_ld, S, npos, C,
                      bias_l2_norm, has_bias, code_out);
   return (int)hipGetLastError();
 }

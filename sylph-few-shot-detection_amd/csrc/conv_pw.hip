@@ -122,7 +122,7 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_pw_kernel(const ConvArgs a) {
   const char* const in1 = reinterpret_cast<const char*>(a.in);
   const char* const in2 = reinterpret_cast<const char*>(a.in2);
   const int nk1 = a.Cin >> 5, nk2 = a.in2 ? (a.Cin2 >> 5) : 0, nk = nk1 + nk2;
-  const int rot_mask = a.pw_rot_mask;  // (largest power of two <= nk) - 1
+  const int rot_mask = a.pw_rot_mask;  // (largest power of two <= nk) - 1: a tile starts its K walk at phase (tile row + N tile) & mask
 
   // ---- loader: runs NST - 1 phases ahead of the MFMAs, across tile boundaries ------------------------------------------------
   int ld_m = bl / n_nt, ld_nt = bl - ld_m * n_nt;  // one division per block
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_pw_kernel(const ConvArgs a) {
     i32x8 d0, d1;
     load_desc(mt, d0, d1);
     const int row0 = d0[0], seg_rows = d0[1], out_W = d0[2], in_row0 = d0[4], in_W = d0[5], in2_row0 = d0[6], in2_W = d0[7];
-    ld_rot = (mt + ld_nt) & rot_mask;
+    ld_rot = ((row0 / BM) + ld_nt) & rot_mask;  // keyed on the tile's place inside its own image: results do not depend on the batch around it
     const bool direct1 = a.stride == 1 && in_W == out_W, direct2 = a.stride2 == 1 && in2_W == out_W;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {

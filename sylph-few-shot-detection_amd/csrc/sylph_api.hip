@@ -169,7 +169,7 @@ struct sylph_ctx {
   void* zeros = nullptr;  // 256 B of zeros (conv out-of-image taps)
   // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
   bool prof = false;
-  struct ProfRec { hipEvent_t a, b; double flops; };
+  struct ProfRec { hipEvent_t a, b; double flops; const char* kern; };
   std::vector<ProfRec> prof_recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
 
@@ -255,6 +255,7 @@ struct Plan {
   float *cg_conv_out = nullptr, *cg_bias_out = nullptr;
   float *re_ctx = nullptr, *re_tok = nullptr, *re_tmp = nullptr, *re_hid = nullptr, *re_cls = nullptr, *re_h = nullptr;
   const float* cur_boxes = nullptr;
+  int cur_shots = 0;  // support images per class of the current sylph_codegen[_classes] call (B = classes x shots)
   float* cur_code_out = nullptr;
 };
 
@@ -562,6 +563,7 @@ static int timed_conv(sylph_ctx* c, DType dt, bool of32, const ConvArgs& a, int 
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -100;
   }
   r.flops = flops;
+  r.kern = (BM == 256 && BN == 256) ? (a.gn_coef ? "conv_hpipe_kernel<true>" : "conv_hpipe_kernel<false>") : "conv_igemm_kernel";  // the names rocprofv3 prints
   (void)hipEventRecord(r.a, s);
   const int rc = launch_conv(dt, of32, a, BM, BN, s);
   (void)hipEventRecord(r.b, s);
@@ -570,7 +572,7 @@ static int timed_conv(sylph_ctx* c, DType dt, bool of32, const ConvArgs& a, int 
 }
 
 // any other launch that should count as conv work in the profile (dedicated stem kernel)
-static int timed_op(sylph_ctx* c, double flops, hipStream_t s, const std::function<int(hipStream_t)>& fn) {
+static int timed_op(sylph_ctx* c, const char* kern, double flops, hipStream_t s, const std::function<int(hipStream_t)>& fn) {
   if (!c->prof) return fn(s);
   sylph_ctx::ProfRec r;
   if (!c->prof_free.empty()) {
@@ -580,6 +582,7 @@ static int timed_op(sylph_ctx* c, double flops, hipStream_t s, const std::functi
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -100;
   }
   r.flops = flops;
+  r.kern = kern;
   (void)hipEventRecord(r.a, s);
   const int rc = fn(s);
   (void)hipEventRecord(r.b, s);
@@ -746,7 +749,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
   const double flops = o.flops >= 0.0 ? o.flops : 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
   if (pw) {
     if (!conv_pw_ok(dt, of32, a)) return fail("internal: conv_pw selected for a layer it cannot run");
-    ops.push_back([a, BM, BN, c, flops](hipStream_t s) { return timed_op(c, flops, s, [=](hipStream_t st) { return launch_conv_pw(a, BM, BN, st); }); });
+    ops.push_back([a, BM, BN, c, flops](hipStream_t s) { return timed_op(c, "conv_pw_kernel", flops, s, [=](hipStream_t st) { return launch_conv_pw(a, BM, BN, st); }); });
     return 0;
   }
   ops.push_back([a, BM, BN, dt, of32, c, flops](hipStream_t s) { return timed_conv(c, dt, of32, a, BM, BN, flops, s); });
@@ -892,8 +895,8 @@ static int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx:
     ba.bk = (const BkTile*)btd;
     ba.n_tiles = (int)bt.size();
     const double fl = 2.0 * (double)B * Hin * Win * (fuse_id ? (256.0 * 64 + 64.0 * 576 + 64.0 * 256) : (64.0 * 64 + 64.0 * 576 + 128.0 * 256));
-    if (fuse_id) ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64(ba, st); }); });
-    else ops.push_back([=](hipStream_t s) { return timed_op(c, fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
+    if (fuse_id) ops.push_back([=](hipStream_t s) { return timed_op(c, "bottleneck64_kernel", fl, s, [=](hipStream_t st) { return launch_bottleneck64(ba, st); }); });
+    else ops.push_back([=](hipStream_t s) { return timed_op(c, "bottleneck64p_kernel", fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
     return 0;
   }
   ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
@@ -950,11 +953,11 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
         void* trash = nullptr;
         RET(c->dalloc(&trash, (size_t)512 * 256 * 16));
         ops.push_back([=](hipStream_t s) {
-          return timed_op(c, fl, s, [=](hipStream_t st) { return launch_stem_pool(x0, wp, scl, shf, po, trash, B, H, W, H2, W2, H4, W4, st); });
+          return timed_op(c, "stem_pool_kernel", fl, s, [=](hipStream_t st) { return launch_stem_pool(x0, wp, scl, shf, po, trash, B, H, W, H2, W2, H4, W4, st); });
         });
       } else {
         ops.push_back([=](hipStream_t s) {
-          return timed_op(c, fl, s, [=](hipStream_t st) { return launch_stem_conv(x0, wp, scl, shf, so, B, H, W, H2, W2, st); });
+          return timed_op(c, "stem_conv_kernel", fl, s, [=](hipStream_t st) { return launch_stem_conv(x0, wp, scl, shf, so, B, H, W, H2, W2, st); });
         });
         ops.push_back([=](hipStream_t s) { return launch_maxpool(dt, so, po, B, H2, W2, 64, H4, W4, s); });
       }
@@ -1182,7 +1185,7 @@ static int build_head(sylph_ctx* c, Plan* P) {
     const float2* bc = box_coef;
     const double fl = 2.0 * (double)rows * cp * 9.0 * 256.0;
     ops.push_back([=](hipStream_t s) {
-      return timed_op(c, fl, s, [=](hipStream_t st) { return launch_gn_pred_taps(xin, 256, bc, wt, cp, bias, 4, 4, taps_ws, plane_rows, pout, 8, sgd, tld, ntl, st); });
+      return timed_op(c, "gn_taps_kernel+tap_gather_kernel", fl, s, [=](hipStream_t st) { return launch_gn_pred_taps(xin, 256, bc, wt, cp, bias, 4, 4, taps_ws, plane_rows, pout, 8, sgd, tld, ntl, st); });
     });
   } else {
     ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
@@ -1303,7 +1306,8 @@ static int build_support(sylph_ctx* c, Plan* P) {
     const float *co = P->cg_conv_out, *bo = P->cg_bias_out;
     const int l2 = c->cfg.cg_bias_l2_norm;
     ops.push_back([=](hipStream_t s) {
-      return launch_codegen_tail(co, 256, bo, 1, S, npos, 256, l2, has_bias, PP->cur_code_out, s);
+      const int shots = PP->cur_shots > 0 ? PP->cur_shots : S;
+      return launch_codegen_tail(co, 256, bo, 1, S / shots, shots, npos, 256, l2, has_bias, PP->cur_code_out, s);
     });
   }
   P->support_built = true;
@@ -2000,7 +2004,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   if (P->cls_coef) {
     if (bn == 32 && P->cls_ld == 256) {  // GroupNorm + ReLU + class-conditional conv in one HBM pass (head_fused.hip)
       const Plan* PP = P;
-      KCHK(timed_op(c, 2.0 * (double)rows * N * 256.0, c->stream, [=](hipStream_t st) {
+      KCHK(timed_op(c, "gn_logits_kernel", 2.0 * (double)rows * N * 256.0, c->stream, [=](hipStream_t st) {
              return launch_gn_logits(PP->cls_feat, 256, PP->cls_coef, PP->code_w, bias, N, PP->logits, Npad, PP->head_segs, PP->head_tiles32,
                                      PP->head_mtiles32, st);
            }), "gn_logits");
@@ -2085,16 +2089,24 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   return 0;
 }
 
-int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
+int sylph_codegen_classes(sylph_ctx* c, const float* boxes, int shots, float* codes_out) {
   Plan* P = c->cur;
   if (!P) return fail("no current batch");
-  if (!boxes || !code_out) return fail("NULL argument");
+  if (!boxes || !codes_out) return fail("NULL argument");
+  if (shots < 1 || P->B % shots != 0) return fail("pooled_features.shape[0] " + std::to_string(P->B) + " Vs batch_size * num_shots: the batch is not a whole number of classes");
+  if (c->cfg.cg_type == 1 && shots != P->B) return fail("ROIEncoder: one class per call (its transformer runs over the class axis, roi_encoder.py:184-186)");
   OwnerScope own(c, P);
   if (c->cfg.cg_type == 1) BUILD(build_support_roienc(c, P), P);
   else BUILD(build_support(c, P), P);
   P->cur_boxes = boxes;
-  P->cur_code_out = code_out;
+  P->cur_code_out = codes_out;
+  P->cur_shots = shots;
   return run_ops(c, P->support_ops, "codegen");
+}
+
+int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {
+  if (!c->cur) return fail("no current batch");
+  return sylph_codegen_classes(c, boxes, c->cur->B, code_out);
 }
 
 int sylph_normalize_codes(sylph_ctx* c, float* codes, int n, const float* weight_norm) {
@@ -2383,6 +2395,31 @@ int sylph_profile_read(sylph_ctx* c, double* conv_ms, double* conv_flops, int64_
   if (conv_flops) *conv_flops = fl;
   if (conv_launches) *conv_launches = (int64_t)c->prof_recs.size();
   c->prof_recs.clear();
+  return 0;
+}
+
+int sylph_profile_read_kernels(sylph_ctx* c, int max_kernels, char* names, double* ms, double* flops, int64_t* launches, int* n_out) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<std::string> order;
+  std::map<std::string, std::tuple<double, double, int64_t>> acc;
+  for (auto& r : c->prof_recs) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+    const std::string k = r.kern ? r.kern : "?";
+    if (!acc.count(k)) order.push_back(k);
+    auto& e = acc[k];
+    std::get<0>(e) += t; std::get<1>(e) += r.flops; std::get<2>(e) += 1;
+    c->prof_free.push_back(std::make_pair(r.a, r.b));
+  }
+  c->prof_recs.clear();
+  int n = 0;
+  for (auto& k : order) {
+    if (n >= max_kernels) break;
+    snprintf(names + (size_t)n * 64, 64, "%s", k.c_str());
+    ms[n] = std::get<0>(acc[k]); flops[n] = std::get<1>(acc[k]); launches[n] = std::get<2>(acc[k]);
+    ++n;
+  }
+  if (n_out) *n_out = n;
   return 0;
 }
 

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "sylph_decode_nms": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_codegen": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sylph_codegen_classes": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "sylph_normalize_codes": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "sylph_reduce_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int]),
     "sylph_conv2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
@@ -73,6 +74,8 @@ PROTOTYPES = {
     "sylph_profile_enable": (c_int, [c_void_p, c_int]),
     "sylph_bench_conv": (c_int, [c_void_p] + [c_int] * 12 + [POINTER(c_float), POINTER(ctypes.c_double)]),
     "sylph_profile_read": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
+    "sylph_profile_read_kernels": (c_int, [c_void_p, c_int, ctypes.c_char_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                           POINTER(c_int64), POINTER(c_int)]),
 }
 
 _LIB = None

@@ -411,6 +411,18 @@ class Engine:
         check(self.L.sylph_codegen(self._ctx, _ptr(bx), _ptr(out)), "codegen")
         return out
 
+    def codegen_classes(self, boxes: torch.Tensor, shots: int) -> torch.Tensor:
+        """Several classes in ONE batch: the current batch holds n_classes * shots support images (class k = images
+        [k * shots, (k + 1) * shots)), boxes (n_classes * shots, 4) -> (n_classes, 257) un-normalised codes."""
+        self._stream()
+        B = self._batch[0]
+        bx = boxes.to(self.device, torch.float32).reshape(-1, 4).contiguous()
+        assert bx.shape[0] == B and B % shots == 0, f"pooled_features.shape[0] {bx.shape[0]} Vs batch_size * num_shots {B}"
+        out = torch.empty(B // shots, 257, device=self.device)
+        self._keep_boxes = bx
+        check(self.L.sylph_codegen_classes(self._ctx, _ptr(bx), int(shots), _ptr(out)), "codegen_classes")
+        return out
+
     def normalize_codes(self, codes: torch.Tensor, weight_norm: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._stream()
         assert codes.is_cuda and codes.dtype == torch.float32 and codes.is_contiguous() and codes.shape[-1] == 257
@@ -530,7 +542,14 @@ class Engine:
         check(self.L.sylph_profile_enable(self._ctx, int(on)), "profile_enable")
 
     def profile_read(self) -> Dict[str, float]:
-        """Summed conv-kernel time (HIP events on the launch stream), algorithmic FLOPs, launches."""
-        ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), c_int64(0)
-        check(self.L.sylph_profile_read(self._ctx, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_read")
-        return {"conv_ms": ms.value, "conv_flops": fl.value, "conv_launches": int(n.value)}
+        """Summed conv-kernel time (HIP events on the launch stream), algorithmic FLOPs, launches -- and the same per kernel
+        (`kernels`: name -> {ms, flops, launches})."""
+        mx = 32
+        names = ctypes.create_string_buffer(mx * 64)
+        ms, fl, ln, n = (ctypes.c_double * mx)(), (ctypes.c_double * mx)(), (c_int64 * mx)(), c_int(0)
+        check(self.L.sylph_profile_read_kernels(self._ctx, mx, names, ms, fl, ln, ctypes.byref(n)), "profile_read_kernels")
+        kern = {}
+        for i in range(n.value):
+            kern[names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()] = {"ms": ms[i], "flops": fl[i], "launches": int(ln[i])}
+        return {"conv_ms": sum(k["ms"] for k in kern.values()), "conv_flops": sum(k["flops"] for k in kern.values()),
+                "conv_launches": sum(k["launches"] for k in kern.values()), "kernels": kern}

@@ -83,19 +83,48 @@ def inference_on_support_set_dataset(model, data_loader, output_dir: str = None)
         if isinstance(model, nn.Module):
             stack.enter_context(inference_context(model))
         stack.enter_context(torch.no_grad())
+        # Classes are grouped into batches of up to SYLPH_SUPPORT_BATCH support images (default 64) that share the backbone and
+        # code-generator launches (model.forward_class_codes); the loader still yields -- and the model API still accepts --
+        # one class per item, as in the reference.  SYLPH_SUPPORT_BATCH=0: one call per class.
+        cap = int(os.environ.get("SYLPH_SUPPORT_BATCH", "64"))
+        batched = cap > 0 and hasattr(model, "forward_class_codes")
+        group: List[Any] = []
+
+        def flush():
+            nonlocal compute
+            if not group:
+                return
+            t0 = time.perf_counter()
+            if batched and len(group) > 1:
+                codes = model.forward_class_codes([g for g in group])
+            else:
+                codes = [model(g, run_type="meta_learn_test_support") for g in group]
+            codes = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in c.items()} for c in codes]  # device sync
+            compute += time.perf_counter() - t0
+            for g, c in zip(group, codes):
+                result = {k: v for k, v in g[0].items() if k != "support_set"}
+                result["class_code"] = c
+                if output_dir is not None:
+                    torch.save(result, os.path.join(output_dir, f"{result['class_name']}.pth"))
+                results.append(result)
+            group.clear()
+
+        n_img = 0
         for idx, inputs in enumerate(data_loader):
             assert len(inputs) == 1, "inputs' batch size is not 1"
             if idx == num_warmup:
+                flush()
+                n_img = 0
                 start_time, compute = time.perf_counter(), 0.0
-            result = {k: v for k, v in inputs[0].items() if k != "support_set"}
-            t0 = time.perf_counter()
-            class_code = model(inputs, run_type="meta_learn_test_support")
-            class_code = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in class_code.items()}  # device sync
-            compute += time.perf_counter() - t0
-            result["class_code"] = class_code
-            if output_dir is not None:
-                torch.save(result, os.path.join(output_dir, f"{result['class_name']}.pth"))
-            results.append(result)
+            k = len(inputs[0]["support_set"])
+            same = not group or (len(group[0][0]["support_set"]) == k and
+                                 group[0][0]["support_set"][0]["image"].shape == inputs[0]["support_set"][0]["image"].shape)
+            if group and (not batched or not same or n_img + k > cap):
+                flush()
+                n_img = 0
+            group.append(inputs)
+            n_img += k
+        flush()
     _log_totals("support", "class code", time.perf_counter() - start_time, compute, total - num_warmup, devices)
     return results
 

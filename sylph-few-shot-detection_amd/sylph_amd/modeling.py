@@ -134,6 +134,12 @@ class CodeGenerator(HipComponent):
         code = self.engine.codegen(boxes)
         return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
 
+    def forward_classes(self, boxes: torch.Tensor, shots: int):
+        """Several classes of `shots` support boxes each in the current batch -> one code dict per class (the launches are
+        shared, the per-class arithmetic is that of __call__)."""
+        codes = self.engine.codegen_classes(boxes, shots)
+        return [{"cls_conv": c[:256].reshape(1, 256, 1, 1), "cls_bias": c[256:257].reshape(1, 1, 1, 1)} for c in codes]
+
 
 @CODE_GENERATOR_REGISTRY.register()
 class ROIEncoder(HipComponent):
@@ -255,6 +261,23 @@ class MetaOneStageDetector(nn.Module):
             assert len(records) // num_shots == 1, "one class per call at inference"
         self.backbone(images=[rec["image"] for rec in records])
         return self.code_generator(torch.cat(boxes, dim=0))
+
+    def forward_class_codes(self, items: List[List[Dict[str, Any]]]) -> List[Dict[str, torch.Tensor]]:
+        """Support-path throughput: the reference (and forward_class_code above) runs ONE class per call; here several classes
+        share the backbone / code-generator launches of one batch (B = classes x shots).  `items`: loader items, each a list of
+        length 1 as in forward_class_code.  Falls back to one call per class when the generator cannot batch classes
+        (ROIEncoder), the shot counts differ or a record carries more than one box."""
+        assert not self.training, "Not for training"
+        recs = [[rec for x in it for rec in x["support_set"]] for it in items]
+        shots = len(recs[0]) if recs else 0
+        batchable = (len(items) > 1 and hasattr(self.code_generator, "forward_classes") and shots > 0
+                     and all(len(it) == 1 and len(r) == shots for it, r in zip(items, recs))
+                     and all(len(rec["instances"].gt_boxes.tensor) == 1 for r in recs for rec in r))
+        if not batchable:
+            return [self.forward_class_code(it) for it in items]
+        self.backbone(images=[rec["image"] for r in recs for rec in r])
+        boxes = torch.cat([rec["instances"].gt_boxes.tensor.reshape(1, 4) for r in recs for rec in r], dim=0)
+        return self.code_generator.forward_classes(boxes, shots)
 
     def normalize_class_code(self, codes: List[Dict]):
         """code_generator.py:877-897 via meta_one_stage_detector.py:256-259 (mutates the list)."""
