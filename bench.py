@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=3)
     ap.add_argument("--no-sweep", action="store_true", help="skip the untimed batch-size sweep / fp32 legs")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-oracle agreement leg")
+    ap.add_argument("--dump-codes", default=None, help="rank 0 writes the gathered, normalised class codes (N x 257) to this .pt file (tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +141,8 @@ def main():
     cls_conv = (codes[:, :256] * args.code_scale).reshape(N, 256, 1, 1).contiguous()
     cls_bias = codes[:, 256].contiguous()
     torch.cuda.synchronize()
+    if args.dump_codes and rank == 0:
+        torch.save({"codes": codes.cpu(), "valid": rows[:, D.F_VALID].cpu()}, args.dump_codes)
     setup = {"codegen_s_first_call": t1 - t0, "code_gather_and_order_s_first_call": t2 - t1, "code_gather_and_order_s": t3 - t2,
              "code_gather_is_collective": world > 1, "support_images": (c1 - c0) * S}
 

@@ -64,6 +64,10 @@ typedef struct sylph_config {
   int head_fc_dim;         /* HEAD.FC_DIM (OUTPUT_DIM 256) */
   int cg_meta_bias;        /* CODE_GENERATOR.META_BIAS: the bias prior is the learned parameter
                               code_generator.code_generator_head.bias_value of the checkpoint (code_generator.py:422-425,856) */
+  int cg_has_weight;       /* len(CODE_GENERATOR.WEIGHT_LAYER) != 0: learned per-shot weights, softmax over the shots of a class
+                              (support_set_cls_weight: conv3x3 256->1 + global average pool; code_generator.py:583-613,766-777) */
+  int cg_has_scale;        /* len(CODE_GENERATOR.SCALE_LAYER) != 0: per-class weight norm "cls_weight_norm"
+                              (support_set_cls_scale: conv3x3 256->1 + global average pool; code_generator.py:615-645,976-993) */
 } sylph_config;
 
 /* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */
@@ -147,6 +151,10 @@ int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
  * (meta_one_stage_detector.py:229-254); per class the arithmetic here is the same (ROIAlign, tower, GroupNorm and the shot mean
  * are per image / per class), only the launches are shared.  CodeGenerator only (ROIEncoder: shots must equal the batch). */
 int sylph_codegen_classes(sylph_ctx* ctx, const float* boxes_dev, int shots, float* codes_out_dev);
+/* With cg_has_scale: the "cls_weight_norm" outputs of the last sylph_codegen[_classes] call (one fp32 per class), the factor
+ * forward_normalize_code multiplies into the L2-normalised code (code_generator.py:838-840,987-993) -> pass them to
+ * sylph_normalize_codes as weight_norm_dev. */
+int sylph_codegen_weight_norm(sylph_ctx* ctx, float* weight_norm_out_dev);
 
 /* Boundary/test entry: the ROIPooler call of the code generator alone (code_generator.py:341-348,928-930: box ->
  * level assignment -> ROIAlignV2 aligned, adaptive sampling, 7x7).  The current batch holds S images, boxes_dev (S,4)

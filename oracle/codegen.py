@@ -40,15 +40,22 @@ def shared_tower(x: torch.Tensor, sd, n_layers: int = 2, prefix: str = CG_PREFIX
 
 
 def code_from_roi_features(roi: torch.Tensor, sd, n_tower_layers: int = 2, bias_l2_norm: bool = False,
-                           has_bias_layer: bool = True, prefix: str = CG_PREFIX) -> Dict[str, torch.Tensor]:
+                           has_bias_layer: bool = True, has_weight_layer: bool = False, has_scale_layer: bool = False,
+                           prefix: str = CG_PREFIX) -> Dict[str, torch.Tensor]:
     """roi (S,256,7,7): ALL S shots belong to one class (eval: num_shot = batch,
-    code_generator.py:788-792).  Returns un-normalised cls_conv (1,OUT,1,1), cls_bias (1,1,1,1)."""
+    code_generator.py:788-792).  Returns un-normalised cls_conv (1,OUT,1,1), cls_bias (1,1,1,1) and, with a SCALE_LAYER,
+    cls_weight_norm (1,1,1,1).  WEIGHT_LAYER: softmax over the shots of a pooled 1-channel head replaces the uniform
+    shot weights (code_generator.py:583-613,766-777,969-979)."""
     f = shared_tower(roi, sd, n_tower_layers, prefix)
     conv_feat = F.conv2d(f, sd[f"{prefix}.support_set_cls_conv.0.weight"],
                          sd[f"{prefix}.support_set_cls_conv.0.bias"], padding=1)
     conv_feat = F.adaptive_avg_pool2d(conv_feat, (1, 1))
     S = roi.shape[0]
     w = torch.full((1, S, 1, 1, 1), 1.0 / S)  # code_generator.py:803-804 (uniform weights)
+    if has_weight_layer:
+        wl = F.adaptive_avg_pool2d(F.conv2d(f, sd[f"{prefix}.support_set_cls_weight.0.weight"],
+                                            sd[f"{prefix}.support_set_cls_weight.0.bias"], padding=1), (1, 1))
+        w = torch.softmax(wl.view(-1, S, 1, 1, 1), dim=1)  # process_weight (code_generator.py:766-777)
     cls_conv = (w * conv_feat.view(1, S, conv_feat.size(1), 1, 1)).sum(dim=1)
     cls_bias = torch.zeros(1, 1, 1, 1)
     if has_bias_layer:
@@ -59,7 +66,12 @@ def code_from_roi_features(roi: torch.Tensor, sd, n_tower_layers: int = 2, bias_
             bias_feat = F.normalize(bias_feat.view(shp[0], shp[1], -1), p=2, dim=2).view(shp)
         bias_feat = F.adaptive_avg_pool2d(bias_feat, (1, 1))
         cls_bias = (w * bias_feat.view(1, S, 1, 1, 1)).sum(dim=1)
-    return {"cls_conv": cls_conv, "cls_bias": cls_bias}
+    out = {"cls_conv": cls_conv, "cls_bias": cls_bias}
+    if has_scale_layer:  # code_generator.py:976-993
+        sc = F.adaptive_avg_pool2d(F.conv2d(f, sd[f"{prefix}.support_set_cls_scale.0.weight"],
+                                            sd[f"{prefix}.support_set_cls_scale.0.bias"], padding=1), (1, 1))
+        out["cls_weight_norm"] = (w * sc.view(1, S, 1, 1, 1)).sum(dim=1)
+    return out
 
 
 def code_generator(features: List[torch.Tensor], boxes: torch.Tensor, sd, strides=(8, 16, 32, 64, 128),

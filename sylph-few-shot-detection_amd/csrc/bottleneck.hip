@@ -52,8 +52,20 @@ constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 #define BK_MFMA_DRAIN2(a0, a1) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1)::"memory")
 #define BK_MFMA_DRAIN3(a0, a1, a2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a0), "+v"(a1), "+v"(a2)::"memory")
 
+// Ablation switches (measurement aids: BK_ONLY = run only phase 1 / 2 / 3 of every tile, BK_NOBAR, BK_NOP1, BK_NOP2, BK_NOX, BK_NOE3,
+// BK_NOSTORE) exist ONLY in builds made with -DSYLPH_ABLATE (tools/build_variant.sh -> lib/variants/): the product library is
+// compiled without it and every switch is forced off here.
+#ifndef SYLPH_ABLATE
+#undef BK_ONLY
+#undef BK_NOBAR
+#undef BK_NOP1
+#undef BK_NOP2
+#undef BK_NOX
+#undef BK_NOE3
+#undef BK_NOSTORE
+#endif
 #ifndef BK_ONLY
-#define BK_ONLY 0  // ablation builds: run only phase 1, 2 or 3 of every tile (4: none)
+#define BK_ONLY 0
 #endif
 #ifdef BK_NOBAR
 #define BK_BAR() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

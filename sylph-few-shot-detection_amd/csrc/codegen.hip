@@ -83,31 +83,54 @@ int launch_roi_align(DType dt, const void* feats, int ld, const LevelDesc* lv_de
   return (int)hipGetLastError();
 }
 
-// conv_out [ncls*S*npos][conv_ld] fp32, bias_out [ncls*S*npos][bias_ld] fp32 (channel 0) -> code_out[ncls][C+1]; one block per class
-// (its S consecutive support images: the arithmetic of a class does not depend on how many classes share the batch)
+// conv_out [ncls*S*npos][conv_ld] fp32, aux_out [ncls*S*npos][aux_ld] fp32 (channel ib: bias head, iw: shot-weight head, is: class-scale
+// head; -1 = absent) -> code_out[ncls][C+1] (+ wnorm_out[ncls] with a scale head); one block per class (its S consecutive support
+// images: the arithmetic of a class does not depend on how many classes share the batch).
+// code_generator.py:766-829: per shot the heads are global-average-pooled, the shots are combined with uniform weights 1/S or, with a
+// WEIGHT_LAYER, with softmax(pooled shot-weight logits) over the shots of the class.
 __global__ __launch_bounds__(256) void codegen_tail_kernel(const float* __restrict__ conv_out, int conv_ld,
-                                                           const float* __restrict__ bias_out, int bias_ld, int S,
-                                                           int npos, int C, int bias_l2_norm, int has_bias,
-                                                           float* __restrict__ code_out) {
+                                                           const float* __restrict__ aux_out, int aux_ld, int ib, int iw, int is, int S,
+                                                           int npos, int C, int bias_l2_norm, float* __restrict__ code_out,
+                                                           float* __restrict__ wnorm_out) {
   conv_out += (size_t)blockIdx.x * S * npos * conv_ld;
-  if (has_bias) bias_out += (size_t)blockIdx.x * S * npos * bias_ld;
+  aux_out += (size_t)blockIdx.x * S * npos * aux_ld;
   code_out += (size_t)blockIdx.x * (C + 1);
-  const float wshot = 1.0f / (float)S;
+  __shared__ float wsh[64];  // per-shot weights (S <= 64)
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    if (iw >= 0) {  // softmax over the shots of the pooled logits (torch.nn.Softmax(dim=1), fp32)
+      float lg = -INFINITY;
+      if (lane < S) {
+        float sum = 0.f;
+        for (int p = 0; p < npos; ++p) sum += aux_out[((size_t)lane * npos + p) * aux_ld + iw];
+        lg = sum / (float)npos;
+      }
+      float mx = lg;
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float e = lane < S ? expf(lg - mx) : 0.f;
+      float den = e;
+      for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+      wsh[lane] = e / den;
+    } else {
+      wsh[lane] = 1.0f / (float)S;
+    }
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float code = 0.f;
     for (int s = 0; s < S; ++s) {
       float sum = 0.f;
       for (int p = 0; p < npos; ++p) sum += conv_out[((size_t)s * npos + p) * conv_ld + c];
-      code += wshot * (sum / (float)npos);
+      code += wsh[s] * (sum / (float)npos);
     }
     code_out[c] = code;
   }
-  if (threadIdx.x < 64) {  // one wave: bias head
+  if (threadIdx.x < 64) {  // one wave: bias and class-scale heads
     const int lane = threadIdx.x;
-    float bias = 0.f;
-    if (has_bias) {
-      for (int s = 0; s < S; ++s) {
-        const float v = lane < npos ? bias_out[((size_t)s * npos + lane) * bias_ld] : 0.f;  // npos <= 64
+    float bias = 0.f, wn = 0.f;
+    for (int s = 0; s < S; ++s) {
+      if (ib >= 0) {
+        const float v = lane < npos ? aux_out[((size_t)s * npos + lane) * aux_ld + ib] : 0.f;  // npos <= 64
         float nrm = 1.f;
         if (bias_l2_norm) {
           float sq = v * v;
@@ -116,18 +139,26 @@ __global__ __launch_bounds__(256) void codegen_tail_kernel(const float* __restri
         }
         float t = v / nrm;
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        bias += wshot * (t / (float)npos);
+        bias += wsh[s] * (t / (float)npos);
+      }
+      if (is >= 0) {
+        float t = lane < npos ? aux_out[((size_t)s * npos + lane) * aux_ld + is] : 0.f;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        wn += wsh[s] * (t / (float)npos);
       }
     }
-    if (lane == 0) code_out[C] = bias;
+    if (lane == 0) {
+      code_out[C] = bias;
+      if (wnorm_out) wnorm_out[blockIdx.x] = wn;
+    }
   }
 }
 
-int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int ncls, int S, int npos, int C,
-                        int bias_l2_norm, int has_bias, float* code_out, hipStream_t s) {
-  if (npos > 64 || ncls < 1) return -1;
-  hipLaunchKernelGGL(codegen_tail_kernel, dim3(ncls), dim3(256), 0, s, conv_out, conv_ld, bias_out, bias_ld, S, npos, C,
-                     bias_l2_norm, has_bias, code_out);
+int launch_codegen_tail(const float* conv_out, int conv_ld, const float* aux_out, int aux_ld, int ib, int iw, int is, int ncls, int S, int npos,
+                        int C, int bias_l2_norm, float* code_out, float* wnorm_out, hipStream_t s) {
+  if (npos > 64 || ncls < 1 || S > 64) return -1;
+  hipLaunchKernelGGL(codegen_tail_kernel, dim3(ncls), dim3(256), 0, s, conv_out, conv_ld, aux_out, aux_ld, ib, iw, is, S, npos, C, bias_l2_norm,
+                     code_out, is >= 0 ? wnorm_out : nullptr);
   return (int)hipGetLastError();
 }
 

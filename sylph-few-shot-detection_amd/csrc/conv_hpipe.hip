@@ -53,6 +53,15 @@
 
 #include "common.h"
 
+// Ablation switches (measurement aids: HP_NOWAITV, HP_NOLDS, HP_NOLOAD, HP_NOEPI) exist ONLY in builds made with -DSYLPH_ABLATE
+// (tools/build_variant.sh -> lib/variants/): the product library is compiled without it and every switch is forced off here.
+#ifndef SYLPH_ABLATE
+#undef HP_NOWAITV
+#undef HP_NOLDS
+#undef HP_NOLOAD
+#undef HP_NOEPI
+#endif
+
 namespace sylph {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -104,8 +104,8 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
 struct LevelDesc { int row0; int H, W; float scale; };  // per (image, level): rows of the feature pyramid
 int launch_roi_align(DType dt, const void* feats, int ld, const LevelDesc* lv_dev, int nlevels, const float* boxes_dev,
                      int S, int out_size, void* out, hipStream_t s);
-int launch_codegen_tail(const float* conv_out, int conv_ld, const float* bias_out, int bias_ld, int ncls, int S, int npos, int C,
-                        int bias_l2_norm, int has_bias, float* code_out, hipStream_t s);
+int launch_codegen_tail(const float* conv_out, int conv_ld, const float* aux_out, int aux_ld, int ib, int iw, int is, int ncls, int S, int npos,
+                        int C, int bias_l2_norm, float* code_out, float* wnorm_out, hipStream_t s);
 int launch_normalize_codes(float* codes, int ncodes, int C, const float* gn_gamma, const float* gn_beta, int post_norm,
                            int l2_norm, float conv_scale, float bias_scale, float bias_prior, const float* weight_norm,
                            hipStream_t s);

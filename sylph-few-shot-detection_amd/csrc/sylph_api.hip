@@ -144,7 +144,8 @@ struct sylph_ctx {
   std::vector<float> level_scales;
   std::vector<ConvLayer> cg_tower;
   std::vector<GNLayer> cg_gn;
-  ConvLayer cg_cls, cg_bias;
+  ConvLayer cg_cls, cg_bias;  // cg_bias: the 1-channel heads stacked on Cout: [bias][shot weight][class scale] (those the config has)
+  int cg_naux = 0, cg_ib = -1, cg_iw = -1, cg_is = -1;  // channel of each head in cg_bias's output (-1: absent)
   GNLayer cg_post;
   float cg_conv_scale = 1.f, cg_bias_scale = 1.f;
   float cg_bias_prior = 0.f;  // bias_value: -log((1 - PRIOR_PROB) / PRIOR_PROB), or the learned parameter with META_BIAS
@@ -252,7 +253,7 @@ struct Plan {
   // support
   LevelDesc* lv_dev = nullptr;
   void *roi = nullptr, *cgA = nullptr, *cgB = nullptr;
-  float *cg_conv_out = nullptr, *cg_bias_out = nullptr;
+  float *cg_conv_out = nullptr, *cg_bias_out = nullptr, *cg_wnorm = nullptr;  // cg_wnorm: cls_weight_norm per class of the last call
   float *re_ctx = nullptr, *re_tok = nullptr, *re_tmp = nullptr, *re_hid = nullptr, *re_cls = nullptr, *re_h = nullptr;
   const float* cur_boxes = nullptr;
   int cur_shots = 0;  // support images per class of the current sylph_codegen[_classes] call (B = classes x shots)
@@ -1274,7 +1275,8 @@ static int build_support(sylph_ctx* c, Plan* P) {
   RET(c->dalloc(&P->cgA, (size_t)S * npos * 256 * e));
   RET(c->dalloc(&P->cgB, (size_t)S * npos * 256 * e));
   RET(c->dalloc((void**)&P->cg_conv_out, (size_t)S * npos * 256 * 4));
-  RET(c->dalloc((void**)&P->cg_bias_out, (size_t)S * npos * 4));
+  RET(c->dalloc((void**)&P->cg_bias_out, (size_t)S * npos * 4 * (c->cg_naux > 0 ? c->cg_naux : 1)));
+  RET(c->dalloc((void**)&P->cg_wnorm, (size_t)S * 4));
   RET(ensure_gn_ws(c, P, S, P->hl[0] * P->wl[0]));
   std::vector<RowSeg> rs;
   for (int s = 0; s < S; ++s) rs.push_back(RowSeg{s * npos, npos});
@@ -1300,14 +1302,15 @@ static int build_support(sylph_ctx* c, Plan* P) {
   }
   ConvOpts oc; oc.pad = 1; oc.out_f32 = true;
   RET(add_conv(c, ops, c->cg_cls, in, 256, P->cg_conv_out, 256, segs, oc));
-  const int has_bias = c->cfg.cg_has_bias;
-  if (has_bias) RET(add_conv(c, ops, c->cg_bias, in, 256, P->cg_bias_out, 1, segs, oc));
+  const int naux = c->cg_naux;
+  if (naux > 0) RET(add_conv(c, ops, c->cg_bias, in, 256, P->cg_bias_out, naux, segs, oc));
   {
     const float *co = P->cg_conv_out, *bo = P->cg_bias_out;
-    const int l2 = c->cfg.cg_bias_l2_norm;
+    const int l2 = c->cfg.cg_bias_l2_norm, ib = c->cg_ib, iw = c->cg_iw, is = c->cg_is;
+    float* wn = P->cg_wnorm;
     ops.push_back([=](hipStream_t s) {
       const int shots = PP->cur_shots > 0 ? PP->cur_shots : S;
-      return launch_codegen_tail(co, 256, bo, 1, S / shots, shots, npos, 256, l2, has_bias, PP->cur_code_out, s);
+      return launch_codegen_tail(co, 256, bo, naux > 0 ? naux : 1, ib, iw, is, S / shots, shots, npos, 256, l2, PP->cur_code_out, wn, s);
     });
   }
   P->support_built = true;
@@ -1449,6 +1452,7 @@ void sylph_config_default(sylph_config* cfg) {
   cfg->cg_type = 0; cfg->tok_num_conv = 2; cfg->tok_num_fc = 2; cfg->enc_layers = 2; cfg->head_num_fc = 2;
   cfg->head_fc_dim = 512;
   cfg->cg_meta_bias = 0;
+  cfg->cg_has_weight = 0; cfg->cg_has_scale = 0;
 }
 
 const char* sylph_last_error(void) { return g_err.c_str(); }
@@ -1670,7 +1674,14 @@ int sylph_finalize_weights(sylph_ctx* c) {
       RET(make_gn(c, cp + ".support_set_shared_tower." + std::to_string(3 * i + 1), &c->cg_gn[i]));
     }
     RET(make_conv_bias(c, {cp + ".support_set_cls_conv.0"}, &c->cg_cls));
-    if (c->cfg.cg_has_bias) RET(make_conv_bias(c, {cp + ".support_set_cls_bias.0"}, &c->cg_bias));
+    {
+      std::vector<std::string> aux;
+      if (c->cfg.cg_has_bias) { c->cg_ib = (int)aux.size(); aux.push_back(cp + ".support_set_cls_bias.0"); }
+      if (c->cfg.cg_has_weight) { c->cg_iw = (int)aux.size(); aux.push_back(cp + ".support_set_cls_weight.0"); }
+      if (c->cfg.cg_has_scale) { c->cg_is = (int)aux.size(); aux.push_back(cp + ".support_set_cls_scale.0"); }
+      c->cg_naux = (int)aux.size();
+      if (!aux.empty()) RET(make_conv_bias(c, aux, &c->cg_bias));
+    }
     if (c->cfg.cg_post_norm) RET(make_gn(c, cp + ".post_norm", &c->cg_post));
     // conv_scale exists iff USE_WEIGHT_SCALE and (CONV_L2_NORM or POST_NORM)  (code_generator.py:372-374)
     c->cg_conv_scale = 1.f;
@@ -2102,6 +2113,15 @@ int sylph_codegen_classes(sylph_ctx* c, const float* boxes, int shots, float* co
   P->cur_code_out = codes_out;
   P->cur_shots = shots;
   return run_ops(c, P->support_ops, "codegen");
+}
+
+int sylph_codegen_weight_norm(sylph_ctx* c, float* out) {
+  Plan* P = c->cur;
+  if (!P || !P->support_built || !P->cg_wnorm) return fail("no code-generator pass on the current batch");
+  if (!c->cfg.cg_has_scale) return fail("CODE_GENERATOR.SCALE_LAYER is empty: there is no cls_weight_norm");
+  const int ncls = P->B / (P->cur_shots > 0 ? P->cur_shots : P->B);
+  HIPCHK(hipMemcpyAsync(out, P->cg_wnorm, (size_t)ncls * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
 }
 
 int sylph_codegen(sylph_ctx* c, const float* boxes, float* code_out) {

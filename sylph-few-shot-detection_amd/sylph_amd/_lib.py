@@ -28,7 +28,7 @@ class SylphConfig(Structure):
         ("cg_tower_layers", c_int), ("cg_has_bias", c_int), ("cg_bias_l2_norm", c_int), ("cg_post_norm", c_int),
         ("cg_conv_l2_norm", c_int), ("cg_use_weight_scale", c_int), ("prior_prob", c_float), ("cand_cap", c_int),
         ("cg_type", c_int), ("tok_num_conv", c_int), ("tok_num_fc", c_int), ("enc_layers", c_int),
-        ("head_num_fc", c_int), ("head_fc_dim", c_int), ("cg_meta_bias", c_int),
+        ("head_num_fc", c_int), ("head_fc_dim", c_int), ("cg_meta_bias", c_int), ("cg_has_weight", c_int), ("cg_has_scale", c_int),
     ]
 
 
@@ -59,6 +59,7 @@ PROTOTYPES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_codegen": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sylph_codegen_classes": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "sylph_codegen_weight_norm": (c_int, [c_void_p, c_void_p]),
     "sylph_normalize_codes": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "sylph_reduce_codes": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int]),
     "sylph_conv2d": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,

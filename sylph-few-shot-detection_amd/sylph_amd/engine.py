@@ -122,8 +122,13 @@ def config_from_cfg(cfg) -> SylphConfig:
     sc.cg_has_bias = int(len(bl) != 0)
     if len(bl) and (len(bl) != 3 or bl[0] not in ("", "none") or bl[1] != "" or int(bl[2]) != 1):
         raise NotImplementedError(f"CODE_GENERATOR.BIAS_LAYER {bl} (only [] or ['', '', 1]: no norm, no ReLU, one conv)")
-    if len(cg.WEIGHT_LAYER) or len(cg.SCALE_LAYER):
-        raise NotImplementedError("CODE_GENERATOR.WEIGHT_LAYER / SCALE_LAYER are not supported")
+    for knob, field in (("WEIGHT_LAYER", "cg_has_weight"), ("SCALE_LAYER", "cg_has_scale")):
+        lay = list(cg.get(knob, []))
+        # [norm, relu, pool]: a 1-channel 3x3 conv + global average pool (code_generator.py:583-645); a norm layer on one channel
+        # cannot be built by the reference either (GroupNorm(32, 1)), the other two entries are not read
+        if len(lay) and (len(lay) != 3 or lay[0] not in ("", "none")):
+            raise NotImplementedError(f"CODE_GENERATOR.{knob} {lay} (only [] or ['', '', 1])")
+        setattr(sc, field, int(len(lay) != 0))
     if bool(cg.COMPRESS_CODE_W_MAX) or bool(cg.CLS_REWEIGHT) or bool(cg.BOX_ON):
         raise NotImplementedError("COMPRESS_CODE_W_MAX / CLS_REWEIGHT / BOX_ON are not supported")
     sc.cg_bias_l2_norm = int(bool(cg.BIAS_L2_NORM))
@@ -276,29 +281,37 @@ class Engine:
         self._stream()
         assert cls_conv.dim() == 4, f"Weight has dimension: {cls_conv.dim()}"
         assert cls_conv.size(2) == 1 and cls_conv.size(3) == 1
-        k = cls_conv.size(1) // 256
-        assert cls_conv.size(1) == 256 * k and k >= 1, f"weight has wrong shape, {tuple(cls_conv.shape)}"
-        assert k == 1 or (self.is_roi_encoder and not raw), "feature.size(1) != weight.size(1)"  # CondConvBasic (head_utils.py:69)
-        w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256 * k)
-        b = cls_bias.to(self.device, torch.float32).reshape(-1).contiguous() if cls_bias is not None else None
-        if self.is_roi_encoder and not raw:
-            # CondConvBlock (head_utils.py:140-162): sum over 256-channel chunks of scale_i * conv(feature, w_i, bias); the
-            # reference indexes the Scale of chunk i+1 with i (head_utils.py:157-161).  conv is linear in (w, bias), so
-            # the block is ONE class-conditional conv with w_eff = sum_i s_i' w_i and bias_eff = (sum_i s_i') bias.
-            if not self._cond_scales_loaded:
-                sc = [1.0 / k] * k  # Scale init of the reference (head_utils.py:131-136): no learned value in the checkpoint
-            else:
-                if len(self.cond_scales) < max(k - 1, 1):
-                    raise ValueError(f"the checkpoint has {len(self.cond_scales)} cond_cls_logits scales; a {256 * k}-channel class "
-                                     f"code needs {max(k - 1, 1)}")
-                sc = list(self.cond_scales)
-            per_chunk = [sc[0]] + [sc[i] for i in range(k - 1)]
-            w = sum(s * w[:, 256 * i:256 * (i + 1)] for i, s in enumerate(per_chunk))
-            b = b * float(sum(per_chunk)) if b is not None else None
-        w = w.contiguous()
-        if b is not None:
-            assert b.numel() == w.size(0)
-        self._codes = (w, b)
+        # The codes of an episode are the same tensors for every query batch: their packed fp32 form is kept (no cast / reshape /
+        # scale kernels in the steady-state step) until a different tensor, or a modified one, arrives.
+        key = (id(cls_conv), cls_conv._version, id(cls_bias), None if cls_bias is None else cls_bias._version, bool(raw))
+        cached = getattr(self, "_codes_key", None) == key
+        if not cached:
+            k = cls_conv.size(1) // 256
+            assert cls_conv.size(1) == 256 * k and k >= 1, f"weight has wrong shape, {tuple(cls_conv.shape)}"
+            assert k == 1 or (self.is_roi_encoder and not raw), "feature.size(1) != weight.size(1)"  # CondConvBasic (head_utils.py:69)
+            w = cls_conv.to(self.device, torch.float32).reshape(cls_conv.size(0), 256 * k)
+            b = cls_bias.to(self.device, torch.float32).reshape(-1).contiguous() if cls_bias is not None else None
+            if self.is_roi_encoder and not raw:
+                # CondConvBlock (head_utils.py:140-162): sum over 256-channel chunks of scale_i * conv(feature, w_i, bias); the
+                # reference indexes the Scale of chunk i+1 with i (head_utils.py:157-161).  conv is linear in (w, bias), so
+                # the block is ONE class-conditional conv with w_eff = sum_i s_i' w_i and bias_eff = (sum_i s_i') bias.
+                if not self._cond_scales_loaded:
+                    sc = [1.0 / k] * k  # Scale init of the reference (head_utils.py:131-136): no learned value in the checkpoint
+                else:
+                    if len(self.cond_scales) < max(k - 1, 1):
+                        raise ValueError(f"the checkpoint has {len(self.cond_scales)} cond_cls_logits scales; a {256 * k}-channel class "
+                                         f"code needs {max(k - 1, 1)}")
+                    sc = list(self.cond_scales)
+                per_chunk = [sc[0]] + [sc[i] for i in range(k - 1)]
+                w = sum(s_ * w[:, 256 * i:256 * (i + 1)] for i, s_ in enumerate(per_chunk))
+                b = b * float(sum(per_chunk)) if b is not None else None
+            w = w.contiguous()
+            if b is not None:
+                assert b.numel() == w.size(0)
+            self._codes = (w, b)
+            self._codes_src = (cls_conv, cls_bias)  # keeps the ids alive
+            self._codes_key = key
+        w, b = self._codes
         self._ncls = w.size(0)
         check(self.L.sylph_fcos_head(self._ctx, _ptr(w), _ptr(b), self._ncls), "fcos_head")
 
@@ -354,10 +367,9 @@ class Engine:
         dev = self.device
         boxes = torch.empty(B, max_out, 4, device=dev)
         scores = torch.empty(B, max_out, device=dev)
-        classes = torch.empty(B, max_out, device=dev, dtype=torch.int32)
-        levels = torch.empty(B, max_out, device=dev, dtype=torch.int32)
+        ints = torch.empty(3, B, max_out, device=dev, dtype=torch.int32)  # classes | levels | candidate ordinals: ONE widening later
+        classes, levels, cand = ints[0], ints[1], ints[2]
         locs = torch.empty(B, max_out, 2, device=dev)
-        cand = torch.empty(B, max_out, device=dev, dtype=torch.int32)
         counts = torch.empty(B + 1, device=dev, dtype=torch.int32)  # [B] = status word
         oh = _iarr([s[0] for s in out_sizes]) if out_sizes is not None else None
         ow = _iarr([s[1] for s in out_sizes]) if out_sizes is not None else None
@@ -377,10 +389,10 @@ class Engine:
         host_counts.copy_(counts, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
-        return (B, boxes, scores, classes, levels, locs, cand, host_counts, done, torch.cuda.current_stream(dev))
+        return (B, boxes, scores, ints, None, locs, None, host_counts, done, torch.cuda.current_stream(dev))
 
     def decode_fetch(self, handle):
-        B, boxes, scores, classes, levels, locs, cand, host_counts, done, stream = handle
+        B, boxes, scores, ints, _, locs, _, host_counts, done, stream = handle
         done.synchronize()
         cnt = host_counts.tolist()
         status = cnt[B]
@@ -389,7 +401,8 @@ class Engine:
         if status & 2:
             raise RuntimeError("sylph decode: more tied detections than max_out")
         with torch.cuda.stream(stream):
-            classes, levels, cand = classes.long(), levels.long(), cand.long()  # 3 launches, then views only
+            wide = ints.long()  # one launch (the reference's index tensors are int64), then views only
+            classes, levels, cand = wide[0], wide[1], wide[2]
         cur = torch.cuda.current_stream(self.device)
         if cur != stream:
             cur.wait_stream(stream)
@@ -421,6 +434,13 @@ class Engine:
         out = torch.empty(B // shots, 257, device=self.device)
         self._keep_boxes = bx
         check(self.L.sylph_codegen_classes(self._ctx, _ptr(bx), int(shots), _ptr(out)), "codegen_classes")
+        return out
+
+    def codegen_weight_norm(self, n_classes: int = 1) -> torch.Tensor:
+        """cls_weight_norm of the last codegen / codegen_classes call (CODE_GENERATOR.SCALE_LAYER), one value per class."""
+        self._stream()
+        out = torch.empty(n_classes, device=self.device)
+        check(self.L.sylph_codegen_weight_norm(self._ctx, _ptr(out)), "codegen_weight_norm")
         return out
 
     def normalize_codes(self, codes: torch.Tensor, weight_norm: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -127,18 +127,27 @@ class CodeGenerator(HipComponent):
 
     def __init__(self, cfg, feature_channels=256, feature_levels=5, strides=None):
         assert feature_channels == 256, "Each level must have the same channel!"
+        self.has_scale = len(cfg.MODEL.META_LEARN.CODE_GENERATOR.get("SCALE_LAYER", [])) != 0  # -> "cls_weight_norm" outputs
 
     def __call__(self, boxes: Optional[torch.Tensor] = None, cls_norm: bool = False, class_codes=None, weight_norm=None):
         if cls_norm:
             return self.engine.normalize_codes(class_codes, weight_norm)
         code = self.engine.codegen(boxes)
-        return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
+        out = {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1, 1, 1, 1)}
+        if self.has_scale:  # code_generator.py:987-999
+            out["cls_weight_norm"] = self.engine.codegen_weight_norm(1).reshape(1, 1, 1, 1)
+        return out
 
     def forward_classes(self, boxes: torch.Tensor, shots: int):
         """Several classes of `shots` support boxes each in the current batch -> one code dict per class (the launches are
         shared, the per-class arithmetic is that of __call__)."""
         codes = self.engine.codegen_classes(boxes, shots)
-        return [{"cls_conv": c[:256].reshape(1, 256, 1, 1), "cls_bias": c[256:257].reshape(1, 1, 1, 1)} for c in codes]
+        outs = [{"cls_conv": c[:256].reshape(1, 256, 1, 1), "cls_bias": c[256:257].reshape(1, 1, 1, 1)} for c in codes]
+        if self.has_scale:
+            wn = self.engine.codegen_weight_norm(len(outs))
+            for o, w in zip(outs, wn):
+                o["cls_weight_norm"] = w.reshape(1, 1, 1, 1)
+        return outs
 
 
 @CODE_GENERATOR_REGISTRY.register()

@@ -97,7 +97,7 @@ def head_state_dict(seed: int = 1, num_classes: int = 60, c: int = 256, num_conv
 
 
 def codegen_state_dict(seed: int = 2, c: int = 256, out_c: int = 256, tower_layers: int = 2,
-                       levels: int = 5) -> Dict[str, torch.Tensor]:
+                       levels: int = 5, weight_scale_layers: bool = False) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     sd = {}
     p = "code_generator.code_generator_head"
@@ -114,6 +114,11 @@ def codegen_state_dict(seed: int = 2, c: int = 256, out_c: int = 256, tower_laye
     sd[f"{p}.support_set_cls_bias.0.bias"] = torch.randn(1, generator=g) * 0.1
     sd[f"{p}.bias_scale.scale"] = torch.tensor([0.9])
     sd[f"{p}.conv_scale.scale"] = torch.tensor([1.3])
+    if weight_scale_layers:  # CODE_GENERATOR.WEIGHT_LAYER / SCALE_LAYER heads (own generator: the weights above stay what they were)
+        g2 = torch.Generator().manual_seed(seed + 1000)
+        for head, bias0 in (("support_set_cls_weight", 0.0), ("support_set_cls_scale", 1.0)):
+            sd[f"{p}.{head}.0.weight"] = _conv(g2, 1, c, 3, std=math.sqrt(4.0 / (9 * c)))
+            sd[f"{p}.{head}.0.bias"] = torch.randn(1, generator=g2) * 0.1 + bias0
     return sd
 
 

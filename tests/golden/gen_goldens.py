@@ -210,6 +210,49 @@ def gen_codegen():
     np.savez_compressed(os.path.join(HERE, "g3_codegen.npz"), **out)
 
 
+def gen_codegen_weight_scale():
+    """CODE_GENERATOR.WEIGHT_LAYER (softmax shot weights) and SCALE_LAYER (cls_weight_norm) of the reference's CodeGenerator
+    (code_generator.py:583-645,766-829,969-999) on g3's S = 2 / 5 inputs, then forward_normalize_code with the weight norm."""
+    from sylph.modeling.code_generator.code_generator import CodeGenerator
+    from ref_shim import Boxes, Instances
+    out = {}
+    sd = W.codegen_state_dict(seed=2, weight_scale_layers=True)
+    out["weights_checksum"] = checksum(sd, "code_generator")
+    H, Wd = 192, 256
+    cfg = make_cfg(False)
+    cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+    cg.WEIGHT_LAYER = ["", "", 1]
+    cg.SCALE_LAYER = ["", "", 1]
+    gen = CodeGenerator(cfg, 256, 5, cfg.MODEL.FCOS.FPN_STRIDES).eval()
+    missing = load_prefixed(gen, sd, "code_generator")
+    assert not [m for m in missing if "support_set_cls" in m], missing
+    g3 = np.load(os.path.join(HERE, "g3_codegen.npz"))
+    recs = []
+    for S in (2, 5):
+        feats = feature_pyramid(S, H, Wd, seed=100 + S)
+        for l, f in enumerate(feats):
+            assert np.array_equal(q8(f), g3[f"s{S}_feat{l}_q8"])  # same inputs as g3 (not stored again)
+        boxes = torch.from_numpy(g3[f"s{S}_boxes"])
+        insts = []
+        for i in range(S):
+            it = Instances((H, Wd))
+            it.gt_boxes = Boxes(boxes[i:i + 1])
+            it.gt_classes = torch.tensor([3])
+            insts.append(it)
+        with torch.no_grad():
+            code = gen(feats, insts)
+        for k in ("cls_conv", "cls_bias", "cls_weight_norm"):
+            out[f"s{S}_{k}"] = code[k].numpy()
+        recs.append({"support_set_target": torch.tensor(len(recs)), "class_name": f"c{S}", "class_code": {k: v.clone() for k, v in code.items()}})
+        print("codegen weight/scale", S, code["cls_conv"].flatten()[:3], code["cls_bias"].flatten(), code["cls_weight_norm"].flatten())
+    with torch.no_grad():
+        normed = gen(None, None, cls_norm=True, class_codes=recs)
+    for i, c in enumerate(normed):
+        out[f"norm{i}_cls_conv"] = c["class_code"]["cls_conv"].numpy()
+        out[f"norm{i}_cls_bias"] = c["class_code"]["cls_bias"].numpy()
+    np.savez_compressed(os.path.join(HERE, "g3c_codegen_weight_scale.npz"), **out)
+
+
 def gen_codegen_s10():
     """BASELINE config C3 support path: 10 shots of one class (mean over shots, code_generator.py:766-829), COCO and
     LVIS (BIAS_L2_NORM) settings, boxes on levels 3..6.  Separate file so that g3_codegen.npz stays bit-stable."""
@@ -334,7 +377,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
-    for fn in (gen_head_decode, gen_decode_variants, gen_codegen, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+    for fn in (gen_head_decode, gen_decode_variants, gen_codegen, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
         if not only or fn.__name__ in only:
             fn()
     print("done")

@@ -126,3 +126,46 @@ def test_rccl_backend_world1_gather_reduce():
     r = subprocess.run([sys.executable, "-c", _NCCL_SCRIPT % {"root": ROOT}], env=env, cwd=ROOT, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _run_bench(nranks, tmp_path, tag, extra=()):
+    """bench.py under torch.distributed.run with `nranks` ranks sharing the ONE GPU of the test box over gloo
+    (SYLPH_BENCH_BACKEND=gloo SYLPH_BENCH_ONE_DEVICE=1): the multi-rank control flow of the script -- class / query shards incl.
+    empty ones, the single code collective, barrier + max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    codes = str(tmp_path / f"codes_{tag}.pt")
+    args = ["bench.py", "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "128", "--width", "160", "--dtype", "f32",
+            "--no-sweep", "--no-parity", "--no-cpu-baseline", "--dump-codes", codes, *extra]
+    env = dict(os.environ, SYLPH_BENCH_BACKEND="gloo", SYLPH_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nranks == 1:
+        cmd = [sys.executable] + args
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + args
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line from rank 0, got {len(lines)}: {res.stdout[-2000:]}"
+    return json.loads(lines[0]), torch.load(codes)
+
+
+def test_bench_multi_rank_control_flow_on_one_device(tmp_path):
+    """2 ranks (3 + 2 classes) and 8 ranks (5 classes -> three empty class shards) against the world-1 run: one JSON
+    line, n_gpus, whole-job value, and the gathered + normalised class codes equal to the single-rank episode (fp32 mode: per-class
+    arithmetic does not depend on which rank computed it)."""
+    one, c1 = _run_bench(1, tmp_path, "w1")
+    assert one["n_gpus"] == 1 and one["config"]["ways"] == 5 and c1["valid"].tolist() == [1.0] * 5
+    for n in (2, 8):
+        out, cn = _run_bench(n, tmp_path, f"w{n}")
+        assert out["n_gpus"] == n and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+        assert abs(out["value"] - n * out["images_per_sec_per_gpu"]) <= 0.006 * n + 0.01  # both are rounded to 2 decimals
+        assert out["episode_setup"]["code_gather_is_collective"] is True
+        assert cn["valid"].tolist() == [1.0] * 5
+        assert torch.equal(cn["codes"], c1["codes"]), f"class codes of the {n}-rank episode differ from the single-rank episode"

@@ -711,3 +711,26 @@ def test_head_bf16_close_to_reference_golden(g1, tag):
             worst = max(worst, float(err))
     print(f"bf16 head vs reference golden ({tag}): worst relative deviation {worst:.4f}")
     assert worst < 4e-2, worst
+
+
+@pytest.mark.parametrize("S", [2, 5])
+def test_codegen_weight_and_scale_layers_match_reference_golden(golden_dir, g3, S):
+    """CODE_GENERATOR.WEIGHT_LAYER / SCALE_LAYER on the HIP path (the three 1-channel heads as one stacked conv, softmax shot weights
+    and the weighted pools in codegen_tail_kernel) against the reference's own outputs (g3c), fp32 mode <= 1e-3; then the
+    normalisation with cls_weight_norm."""
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g3c_codegen_weight_scale.npz"))
+    cfg = _cfg(**{"MODEL.META_LEARN.CODE_GENERATOR.WEIGHT_LAYER": ["", "", 1], "MODEL.META_LEARN.CODE_GENERATOR.SCALE_LAYER": ["", "", 1]})
+    eng = _engine("f32", cfg)
+    assert int(eng.sc.cg_has_weight) == 1 and int(eng.sc.cg_has_scale) == 1
+    eng.load_state_dict(W.codegen_state_dict(seed=2, weight_scale_layers=True))
+    eng.import_pyramid(_feats(g3, f"s{S}_feat"), (192, 256))
+    code = eng.codegen(torch.from_numpy(g3[f"s{S}_boxes"]))
+    wn = eng.codegen_weight_norm(1)
+    np.testing.assert_allclose(code[:256].cpu().numpy(), g[f"s{S}_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(code[256].item(), g[f"s{S}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(wn.cpu().numpy(), g[f"s{S}_cls_weight_norm"].reshape(-1), atol=1e-3, rtol=1e-3)
+    i = {2: 0, 5: 1}[S]
+    normed = eng.normalize_codes(code.reshape(1, 257).clone().contiguous(), wn).cpu().numpy()
+    np.testing.assert_allclose(normed[0, :256], g[f"norm{i}_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(normed[0, 256], g[f"norm{i}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)

@@ -168,3 +168,19 @@ def test_roi_encoder_matches_reference(golden_dir, S):
     assert out["cls_conv"].shape == (1, 256, 1, 1) and out["cls_bias"].shape == (1,)
     np.testing.assert_allclose(out["cls_conv"].numpy(), g[f"s{S}_cls_conv"], atol=5e-5, rtol=5e-5)
     np.testing.assert_allclose(out["cls_bias"].numpy(), g[f"s{S}_cls_bias"], atol=5e-5, rtol=5e-5)
+
+
+@pytest.mark.parametrize("S", [2, 5])
+def test_codegen_weight_and_scale_layers_match_reference(golden_dir, g3, S):
+    """CODE_GENERATOR.WEIGHT_LAYER (softmax shot weights) + SCALE_LAYER (cls_weight_norm), code_generator.py:583-645,766-829,969-999,
+    against the reference module's own outputs on g3's inputs, then forward_normalize_code with the weight norm."""
+    g = _load(golden_dir, "g3c_codegen_weight_scale.npz")
+    sd = W.codegen_state_dict(seed=2, weight_scale_layers=True)
+    assert abs(_checksum(sd, "code_generator") - float(g["weights_checksum"])) < 1e-3
+    out = CG.code_generator(_feats(g3, f"s{S}_feat"), torch.from_numpy(g3[f"s{S}_boxes"]), sd, has_weight_layer=True, has_scale_layer=True)
+    for k in ("cls_conv", "cls_bias", "cls_weight_norm"):
+        np.testing.assert_allclose(out[k].numpy(), g[f"s{S}_{k}"], atol=TOL, rtol=TOL)
+    i = {2: 0, 5: 1}[S]
+    conv, bias = CG.normalize_code(out["cls_conv"], out["cls_bias"], sd, cls_weight_norm=out["cls_weight_norm"])
+    np.testing.assert_allclose(conv.numpy(), g[f"norm{i}_cls_conv"], atol=TOL, rtol=TOL)
+    np.testing.assert_allclose(bias.numpy(), g[f"norm{i}_cls_bias"], atol=TOL, rtol=TOL)
