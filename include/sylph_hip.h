@@ -117,6 +117,10 @@ int sylph_export_pyramid(sylph_ctx* ctx, int level, float* out_nchw_dev);
  * CondConvBasic sylph/modeling/meta_fcos/head_utils.py:60-81).  cls_conv_dev: (N,256) fp32,
  * cls_bias_dev: (N) fp32 or NULL.  Results stay in the context (see sylph_export_head). */
 int sylph_fcos_head(sylph_ctx* ctx, const float* cls_conv_dev, const float* cls_bias_dev, int N);
+/* MetaFCOSHead.forward with support_set_per_class_code = None -> forward_base_train (fcos.py:543-578): the towers and the checkpoint's
+ * OWN classifier `cls_logits` (nn.Conv2d(256, NUM_CLASSES, CLS_LOGITS_KERNEL_SIZE 1 or 3, padding k // 2), fcos.py:418-427) -- the base
+ * detector (run_type None) and evaluation with the pretrained codes.  *num_classes receives NUM_CLASSES. */
+int sylph_fcos_head_pretrained(sylph_ctx* ctx, int* num_classes);
 /* logits (B,N,h,w), reg (B,4,h,w) = relu(scale_l*bbox_pred), ctr (B,1,h,w), iou (B,1,h,w); NULL skips. */
 int sylph_export_head(sylph_ctx* ctx, int level, float* logits_nchw_dev, float* reg_nchw_dev, float* ctr_nchw_dev,
                       float* iou_nchw_dev);

@@ -140,6 +140,8 @@ struct sylph_ctx {
   std::vector<GNLayer> pair_gn;
   bool paired = false;
   ConvLayer pred;  // bbox_pred(4) + ctrness(1) + iou_overlap(1)
+  ConvLayer cls_logits;  // the base detector's own classifier (fcos.py:418-427), 1x1 or 3x3, when the checkpoint carries it
+  bool has_cls_logits = false;
   void* pred_taps = nullptr;  // bf16 [64][256]: row kh * sw + kw * Cout + n = pred weight W[n][kh][kw][:] (head_fused.hip), bf16 mode only
   std::vector<float> level_scales;
   std::vector<ConvLayer> cg_tower;
@@ -246,6 +248,8 @@ struct Plan {
   DecodeSeg* dsegs = nullptr;
   DecodeBuffers dbuf;
   bool decode_built = false;
+  std::vector<OpFn> cls_logits_ops;  // the checkpoint's cls_logits conv on this plan's cls tower output (sylph_fcos_head_pretrained)
+  const float* cls_logits_dst = nullptr;  // the logits buffer those ops were built for
   int cand_cap = 0, pool_cap = 0;
   ImageOut* img_out_dev = nullptr;
   ImageOut* img_out_host = nullptr;
@@ -1639,6 +1643,13 @@ int sylph_finalize_weights(sylph_ctx* c) {
       c->paired = true;
     }
     RET(make_conv_bias(c, {hp + ".bbox_pred", hp + ".ctrness", hp + ".iou_overlap"}, &c->pred));
+    if (find_w(c, hp + ".cls_logits.weight") && find_w(c, hp + ".cls_logits.bias")) {
+      const HostTensor* w = find_w(c, hp + ".cls_logits.weight");
+      if (w->shape.size() == 4 && w->shape[1] == 256 && w->shape[2] == w->shape[3] && (w->shape[2] == 1 || w->shape[2] == 3)) {
+        RET(make_conv_bias(c, {hp + ".cls_logits"}, &c->cls_logits));
+        c->has_cls_logits = true;
+      }
+    }
     c->pred_taps = nullptr;
     if (c->dt == DT_BF16 && c->pred.KH == 3 && c->pred.KW == 3 && c->pred.Cin == 256 && 3 * ((3 * c->pred.Cout + 3) & ~3) <= 64) {
       // the same weights stacked for the fused GroupNorm + prediction pass: row kh * sw + kw * Cout + n, sw = roundup4(3 * Cout)
@@ -2036,6 +2047,28 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   a.Cin = 256; a.Cout = N; a.KH = 1; a.KW = 1; a.stride = 1; a.pad = 0;
   a.in_ld = P->cls_ld; a.out_ld = Npad;
   KCHK(timed_conv(c, c->dt, true, a, BM, bn, 2.0 * (double)rows * N * 256.0, c->stream), "cond_cls_logits");
+  return 0;
+}
+
+int sylph_fcos_head_pretrained(sylph_ctx* c, int* num_classes) {
+  Plan* P = c->cur;
+  if (!P) return fail("no current batch");
+  if (!c->has_cls_logits) return fail("the checkpoint has no proposal_generator.fcos_head.cls_logits (1x1 or 3x3, 256 input channels)");
+  OwnerScope own(c, P);
+  BUILD(build_head(c, P), P);
+  const int N = c->cls_logits.Cout;
+  RET(ensure_logits(c, P, N));
+  if (c->cls_logits.Cout_pad != P->logits_ld) return fail("internal: cls_logits padding");
+  if (P->cls_logits_dst != P->logits) {  // (re)build the conv launch for this plan's buffers
+    P->cls_logits_ops.clear();
+    ConvOpts o; o.pad = c->cls_logits.KH / 2; o.out_f32 = true;
+    RET(add_conv(c, P->cls_logits_ops, c->cls_logits, P->cls_feat, P->cls_ld, P->logits, P->logits_ld, pyramid_segs(c, P), o));
+    P->cls_logits_dst = P->logits;
+  }
+  RET(run_ops(c, P->head_ops, "fcos_head"));
+  if (P->cls_coef) KCHK(P->cls_apply(c->stream), "gn_apply (cls tower, last layer)");
+  RET(run_ops(c, P->cls_logits_ops, "cls_logits"));
+  if (num_classes) *num_classes = N;
   return 0;
 }
 

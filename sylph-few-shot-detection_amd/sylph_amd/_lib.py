@@ -52,6 +52,7 @@ PROTOTYPES = {
                                      POINTER(c_void_p)]),
     "sylph_export_pyramid": (c_int, [c_void_p, c_int, c_void_p]),
     "sylph_fcos_head": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "sylph_fcos_head_pretrained": (c_int, [c_void_p, POINTER(c_int)]),
     "sylph_export_head": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_import_head": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_roi_align": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -68,8 +68,8 @@ def config_from_cfg(cfg) -> SylphConfig:
     if not bool(m.META_LEARN.EPISODIC_LEARNING):
         # plain base detector (meta_one_stage_detector.py:52-58: no code generator is built): the head runs the checkpoint's
         # own 1x1 cls_logits through the class-conditional conv, always with its bias
-        if int(f.get("CLS_LOGITS_KERNEL_SIZE", 3)) != 1:
-            raise NotImplementedError("base-detector inference needs MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 1")
+        if int(f.get("CLS_LOGITS_KERNEL_SIZE", 3)) not in (1, 3):
+            raise NotImplementedError("base-detector inference needs MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE 1 or 3")
         sc.cond_use_bias = 1
         return sc
     cg = m.META_LEARN.CODE_GENERATOR
@@ -314,6 +314,14 @@ class Engine:
         w, b = self._codes
         self._ncls = w.size(0)
         check(self.L.sylph_fcos_head(self._ctx, _ptr(w), _ptr(b), self._ncls), "fcos_head")
+
+    def head_pretrained(self) -> int:
+        """forward_base_train (fcos.py:543-578): towers + the checkpoint's own cls_logits conv (1x1 or 3x3) -> number of classes."""
+        self._stream()
+        n = c_int(0)
+        check(self.L.sylph_fcos_head_pretrained(self._ctx, ctypes.byref(n)), "fcos_head_pretrained")
+        self._ncls = n.value
+        return n.value
 
     def export_head(self):
         self._stream()

@@ -116,6 +116,12 @@ class MetaFCOS(HipComponent):
         self.engine.head(cls_conv, cls_bias, raw=raw)
         return self.engine.decode(out_sizes)
 
+    def forward_pretrained(self, out_sizes):
+        """support_set_per_class_code = None (fcos.py:543-578): the checkpoint's own cls_logits conv, any kernel size the library
+        packed (1x1 / 3x3)."""
+        self.engine.head_pretrained()
+        return self.engine.decode(out_sizes)
+
 
 @CODE_GENERATOR_REGISTRY.register()
 class CodeGenerator(HipComponent):
@@ -339,15 +345,16 @@ class MetaOneStageDetector(nn.Module):
             pre = getattr(self, "_pretrained_cls_logits", None)
             if pre is None:
                 raise ValueError("class_code is None and the checkpoint has no proposal_generator.fcos_head.cls_logits weights")
-            if pre[0].dim() != 4 or pre[0].shape[2:] != (1, 1):
-                raise NotImplementedError(f"pretrained cls_logits with kernel {tuple(pre[0].shape[2:])}: only 1x1 "
-                                          "(MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 1) is supported")
+            if pre[0].dim() != 4 or tuple(pre[0].shape[2:]) not in ((1, 1), (3, 3)):
+                raise NotImplementedError(f"pretrained cls_logits with kernel {tuple(pre[0].shape[2:])}: only 1x1 and 3x3 "
+                                          "(MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE) are supported")
             if self.episodic_learning and not bool(self.cfg.MODEL.META_LEARN.CODE_GENERATOR.USE_BIAS):
                 raise NotImplementedError("pretrained cls_logits needs the bias path of the class-conditional conv (USE_BIAS)")
             class_codes = {"cls_conv": pre[0].to(self.device), "cls_bias": pre[1].to(self.device)}
         w, b = class_codes["cls_conv"], class_codes.get("cls_bias")
         assert w.dim() == 4, f"Weight has dimension: {w.dim()}"
         assert w.size(1) == 256
+        conv3 = pretrained and tuple(w.shape[2:]) == (3, 3)  # a 3x3 cls_logits is a real conv, not a class-conditional 1x1
         if all("image_u8" in x for x in batched_inputs):
             # fused input pipeline: the original uint8 HWC image + its ResizeShortestEdge target; resize,
             # BGR conversion, normalisation and padding run in one HIP kernel (sylph_preprocess_u8)
@@ -357,7 +364,10 @@ class MetaOneStageDetector(nn.Module):
             sizes = self.backbone(images=[x["image"] for x in batched_inputs])
         out_sizes = [(int(x.get("height", s[0])), int(x.get("width", s[1]))) for x, s in zip(batched_inputs, sizes)]
         # the checkpoint's own cls_logits are a plain conv: no CondConvBlock Scale on a ROIEncoder model
-        dets = self.proposal_generator(w, b, out_sizes, raw=True) if pretrained else self.proposal_generator(w, b, out_sizes)
+        if conv3:
+            dets = self.proposal_generator.forward_pretrained(out_sizes)
+        else:
+            dets = self.proposal_generator(w, b, out_sizes, raw=True) if pretrained else self.proposal_generator(w, b, out_sizes)
         results = []
         for d, osz in zip(dets, out_sizes):
             r = Instances(osz)

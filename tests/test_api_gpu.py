@@ -460,3 +460,49 @@ def test_support_classes_batched_equal_one_class_per_call(sd, dtype):
     assert [int(r["support_set_target"]) for r in grouped] == [0, 1, 2] and [r["class_name"] for r in grouped] == [it[0]["class_name"] for it in items]
     for r, b in zip(grouped, many):
         assert torch.equal(r["class_code"]["cls_conv"], b["cls_conv"].cpu())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_base_detector_with_3x3_cls_logits(sd, dtype):
+    """MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 3 (the adet-style classifier, fcos.py:418-427; Sylph's default_configs.py:48 switches it to 1):
+    run_type None on a non-episodic model runs `cls_logits(cls_tower)` as a real 3x3 conv (sylph_fcos_head_pretrained).  fp32: logits
+    <= 1e-3 of the oracle's tower + F.conv2d, detections = the oracle decoder on those head outputs; bf16: finite + close logits."""
+    from oracle import backbone as OB, decode as OD, head as OH
+    from sylph_amd import synthetic as W
+    from sylph_amd.runner import MetaFCOSRunner
+    g = torch.Generator().manual_seed(77)
+    sd3 = {k: v for k, v in sd.items() if not k.startswith("code_generator.")}
+    w3 = torch.randn(7, 256, 3, 3, generator=g) * (1.0 / (9 * 256)) ** 0.5 * 2.0
+    b3 = torch.full((7,), -2.0) + 0.2 * torch.randn(7, generator=g)
+    sd3["proposal_generator.fcos_head.cls_logits.weight"], sd3["proposal_generator.fcos_head.cls_logits.bias"] = w3, b3
+    r = MetaFCOSRunner()
+    cfg = r.get_default_cfg()
+    cfg.MODEL.META_LEARN.EPISODIC_LEARNING = False
+    cfg.MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 3
+    cfg.MODEL.FCOS.NUM_CLASSES = 7
+    base = r.build_model(cfg, dtype=dtype)
+    base.load_state_dict(sd3)
+    base.eval()
+    imgs = W.synthetic_images(2, 96, 128, seed=23)
+    batch = [{"image": im, "height": 96, "width": 128} for im in imgs]
+    got = base(batch)
+    lo, rg, ct, io = [[t.cpu() for t in ts] for ts in base.engine.export_head()]
+    x0, sizes = OB.preprocess(imgs)
+    feats = OB.backbone_fpn(x0, sd3, 50)
+    tol = 1e-3 if dtype == "f32" else 6e-2
+    for l in range(5):
+        t = OH.tower(feats[l], sd3, "proposal_generator.fcos_head.cls_tower")
+        ref = torch.nn.functional.conv2d(t, w3, b3, padding=1)
+        assert tuple(lo[l].shape) == tuple(ref.shape)
+        assert (lo[l] - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), l
+    if dtype == "f32":
+        want = OD.predict_proposals(lo, rg, ct, io)
+        for i in range(2):
+            wv = OD.detector_postprocess(want[i], sizes[i], 96, 128)
+            inst = got[i]["instances"]
+            assert len(inst) == wv["scores"].numel() > 0
+            np.testing.assert_array_equal(inst.pred_classes.cpu().numpy(), wv["pred_classes"].numpy())
+            np.testing.assert_array_equal(inst.locations.cpu().numpy(), wv["locations"].numpy())
+            np.testing.assert_allclose(inst.scores.cpu().numpy(), wv["scores"].numpy(), atol=1e-5)
+    else:
+        assert all(torch.isfinite(o["instances"].scores).all() for o in got)

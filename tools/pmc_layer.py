@@ -17,6 +17,9 @@ LAYERS = {
     "fpn.out3": (100, 168, 256, 256, 3, 1, 1, 0, 0),
     "res4.conv2": (50, 84, 256, 256, 3, 1, 1, 0, 0),
     "res3.conv2": (100, 168, 128, 128, 3, 1, 1, 0, 0),
+    "res4.conv1": (50, 84, 1024, 256, 1, 1, 0, 0, 0),   # conv_pw_kernel<128, 256>
+    "res5.conv1": (25, 42, 2048, 512, 1, 1, 0, 0, 0),   # conv_pw_kernel<128, 256>
+    "res4.conv3": (50, 84, 256, 1024, 1, 1, 0, 1, 0),   # conv_igemm (residual)
 }
 name = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16

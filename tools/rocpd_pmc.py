@@ -3,7 +3,7 @@
 
     python tools/rocpd_pmc.py <fetch.db> <write.db> <batch> [out.json]
 
-Sums the counters over the conv launches (conv_igemm / conv_hpipe / bottleneck64[p] / stem_pool / gn_logits / gn_taps + tap_gather) of the LAST query
+Sums the counters over the conv launches (conv_igemm / conv_hpipe / conv_pw / bottleneck64[p] / stem_pool / gn_logits / gn_taps + tap_gather) of the LAST query
 step (from the last preprocess_kernel dispatch on); also reports the sum over EVERY kernel of that step.  Units/corrections as MI355X_MICROARCH.md prescribes: the counters are
 KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
 used as is (checked here against preprocess_kernel, whose write volume is known exactly)."""
@@ -19,7 +19,7 @@ def last_step(dbfile, counter):
     idx = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]][-1]
     step = rows[idx:]
     # every launch bench.py times as conv work (sylph_profile_*): the conv kernels proper and the fused passes that replace convs
-    CONV = ("conv_igemm_kernel", "conv_hpipe_kernel", "bottleneck64", "stem_pool_kernel", "stem_conv_kernel", "gn_logits_kernel",
+    CONV = ("conv_igemm_kernel", "conv_hpipe_kernel", "conv_pw_kernel", "bottleneck64", "stem_pool_kernel", "stem_conv_kernel", "gn_logits_kernel",
             "gn_taps_kernel", "tap_gather_kernel")
     conv = [r for r in step if any(k in r[0] for k in CONV)]
     pre = step[0][1]
