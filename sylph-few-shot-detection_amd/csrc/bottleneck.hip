@@ -79,7 +79,21 @@ constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 #endif
 }  // namespace
 
+// NR1 / NR2 / NR3: 32-row MFMA tiles a wave processes in P1 (halo rows) / P2 / P3 (patch positions); XR = NR1 * 64 halo rows.
+//   <3, 2, 4, false>: patches of <= 128 positions, ONE 96-KiB halo buffer, the next halo issued after conv1 (round 2);
+//   <2, 1, 2, true>:  patches of <= 64 positions (8 x 8), TWO 64-KiB halo buffers: the next patch's halo is issued at the TOP of
+//                     a tile, a whole tile ahead, and lands under conv1 / conv2 / conv3 of the current one (round-3 experiment: the
+//                     identity block is limited by the halo round trip, 0.80 ms of compute in 1.29 ms).  MFMA work per position is
+//                     the same (P1 recomputes 128 / 64 halo rows per position instead of 192 / 120, P2 / P3 run full 64 / 64 tiles
+//                     instead of 120 / 128), but 2.2 x as many tiles pay the per-tile fixed costs: measured 1.56 ms vs 1.31 ms per
+//                     launch at B = 64.  Parity-clean, kept behind SYLPH_BK_SMALL=1 for A/B runs; NOT the default.
+template <int NR1, int NR2, int NR3, bool DB>
 __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckArgs a) {
+  constexpr int XR = NR1 * 64;                     // halo rows of a buffer
+  constexpr int XBB = XR * 512;                    // one halo buffer
+  constexpr int T1O = (DB ? 2 : 1) * XBB;          // t1 halo [XR][64 ch] (pitch TP); t2 aliases it
+  constexpr int BNO = T1O + XR * TP;
+  constexpr int NST = NR3 * 8;                     // stores per lane and tile
   typedef bf16_t T;
   typedef int i32x8 __attribute__((ext_vector_type(8)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));  // ext_vector LDS accesses: hipcc adds no vmcnt(0) for them beside LDS-DMA
@@ -91,9 +105,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
   char* const trash = reinterpret_cast<char*>(a.trash) + ((size_t)blockIdx.x * 256 + tid) * 128;  // 128 B per thread: the 8 stores of a row tile
-  char* const xb = smem;
-  char* const t1 = smem + T1_OFF;
-  float* const bn = reinterpret_cast<float*>(smem + BN_OFF);
+  char* xb = smem;  // the current tile's halo buffer
+  char* const t1 = smem + T1O;
+  float* const bn = reinterpret_cast<float*>(smem + BNO);
 
   // ---- weights -> registers (plain loads, before any LDS-DMA exists) -------------------------------------------------------
   const int ct1 = wave >> 1;  // P1 / P2: this wave's 32 mid channels
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   // are loaded from a clamped (valid) address instead of a zero page: whatever lands there is never used -- P1 masks t1 to 0
   // for those rows (they are conv2's zero padding) and the residual is only read at stored positions.
   const int xr = tid >> 5, xs = tid & 31;
-  auto issue_x = [&](const i32x8 d) {
+  auto issue_x = [&](const i32x8 d, char* dstb) {
     const int row0 = d[0], H = d[1], W = d[2], oy0 = d[3] >> 16, ox0 = d[3] & 0xffff, HW2 = d[5] + 2, HR = (d[4] + 2) * HW2;
     const int nr = (HR + 7) >> 3;  // rows >= HR are never read by P2
     int hy = 0, hx = xr;
@@ -154,15 +168,15 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       const int h = r * 8 + xr;
       const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
       const unsigned off = ((unsigned)(row0 + iy * W + ix) << 9) + (unsigned)((xs ^ (h & 31)) << 4);  // bytes; x < 4 GiB (checked by the host)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(xb + r * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(dstb + r * 4096 + wave * 1024), 16, 0, 0);
       hx += 8;
     }
   };
 
   int t = tile_of(0);
   i32x8 td = load_tile(t < a.n_tiles ? t : 0);
-  if (t < a.n_tiles) issue_x(td);
-  const int rb1 = (wave & 1) * 3, rb2 = (wave & 1) * 2;  // first row tile of this wave in P1 (3 tiles) / P2 (2 tiles)
+  if (t < a.n_tiles) issue_x(td, xb);
+  const int rb1 = (wave & 1) * NR1, rb2 = (wave & 1) * NR2;  // first row tile of this wave in P1 (3 tiles) / P2 (2 tiles)
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   // bf16 pair: ReLU as a packed signed-16-bit max with 0 (sign bit set <=> negative), then AND with a keep mask
   auto relu_pk = [](unsigned u, unsigned keep) {
@@ -189,8 +203,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     // the halo loads of the next one (lanes without a valid position write to a private trash slot instead of being masked
     // off), so vmcnt(32) leaves the previous tile's stores -- and their ~2 us of write acknowledgement -- in flight
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     BK_BAR();  // ... for every wave; t1 / t2 of the previous tile are free
+    if (DB) {
+      // the other buffer was last read in P1 / the residual copy of the previous tile: free.  Its refill is in flight during this
+      // whole tile; the vmcnt wait above (next iteration) leaves exactly this tile's NST stores, issued after it, outstanding.
+      char* const other = xb == smem ? smem + XBB : smem;
+      if (t_next < a.n_tiles) issue_x(td_next, other);
+    }
 
     // ===== P1: t1 = relu(bn1(x_halo . W1^T)), row tiles rb1 .. rb1+2, channels ct1 ===========================================
     // (lz*: zero, opaque to the compiler and re-made per tile and phase: LDS addresses would otherwise be hoisted out of the tile
@@ -199,20 +219,20 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       int lz1;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz1));
       const int l31a = l31 + lz1;
-      f32x16 acc1[3];
+      f32x16 acc1[NR1];
       // the three row tiles are 32 rows = 16 KiB apart and share the swizzle key (row & 31 == l31): one address per k-step,
       // the tiles are immediate offsets
       const char* abase = xb + (rb1 * 32 + l31a) * 512;
       const int akey = (l31a ^ lh) << 4;
       constexpr int D1 = 3;  // fragment ring: reads run D1 - 1 k-steps ahead of the MFMAs (one wave per SIMD: nothing else hides LDS latency)
-      bf16x8 af[D1][3];
+      bf16x8 af[D1][NR1];
 #pragma unroll
       for (int ks = 0; ks < D1 - 1; ++ks) {
         const char* ap = abase + ((ks * 32) ^ akey);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16384);
+        for (int i = 0; i < NR1; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16384);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 3 * (D1 - 1), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NR1 * (D1 - 1), 0);
 #ifdef BK_NOP1
       constexpr int K1 = 4;
 #else
@@ -223,18 +243,19 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
         if (ks + D1 - 1 < 16) {
           const char* ap = abase + (((ks + D1 - 1) * 32) ^ akey);
 #pragma unroll
-          for (int i = 0; i < 3; ++i) af[(ks + D1 - 1) % D1][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16384);
+          for (int i = 0; i < NR1; ++i) af[(ks + D1 - 1) % D1][i] = *reinterpret_cast<const bf16x8*>(ap + i * 16384);
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NR1; ++i) {
           if (ks == 0) BK_MFMA0(acc1[i], W1f[ks], af[ks % D1][i]);
           else BK_MFMA(acc1[i], W1f[ks], af[ks % D1][i]);
         }
       }
-      BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
+      if constexpr (NR1 == 3) BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
+      else BK_MFMA_DRAIN2(acc1[0], acc1[1]);
       const float* sp = s1 + ct1 * 32 + 4 * lh;  // b1 = s1 + 64
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NR1; ++i) {
         const int h = (rb1 + i) * 32 + l31a;
         const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
         const bool in1 = h < HR && (unsigned)(oy0 - 1 + hy) < (unsigned)IH && (unsigned)(ox0 - 1 + hx) < (unsigned)IW;
@@ -251,12 +272,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       }
     }
     // residual values of this lane's conv3 outputs (positions rt * 32 + l31, channels 64 wave + 32 j + 8 gq + 4 lh ..): halo -> registers
-    u32x2 res[32];
-    char* yptr[4];
+    u32x2 res[NR3 * 8];
+    char* yptr[NR3];
     int lzr;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lzr));
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < NR3; ++rt) {
       const int m = rt * 32 + l31 + lzr;
       const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
       const bool pv = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
@@ -273,12 +294,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]),
                    "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
-    asm volatile(""
-                 : "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]), "+v"(res[20]), "+v"(res[21]), "+v"(res[22]), "+v"(res[23]),
-                   "+v"(res[24]), "+v"(res[25]), "+v"(res[26]), "+v"(res[27]), "+v"(res[28]), "+v"(res[29]), "+v"(res[30]), "+v"(res[31]));
+    if constexpr (NR3 == 4)
+      asm volatile(""
+                   : "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]), "+v"(res[20]), "+v"(res[21]), "+v"(res[22]), "+v"(res[23]),
+                     "+v"(res[24]), "+v"(res[25]), "+v"(res[26]), "+v"(res[27]), "+v"(res[28]), "+v"(res[29]), "+v"(res[30]), "+v"(res[31]));
     BK_BAR();  // t1 complete; every wave is done with the x halo
 #ifndef BK_NOX
-    if (t_next < a.n_tiles) issue_x(td_next);
+    if (!DB && t_next < a.n_tiles) issue_x(td_next, xb);
 #endif
 
     // ===== P2: t2 = relu(bn2(conv3x3(t1))), row tiles rb2, rb2+1, channels ct1 ===============================================
@@ -288,10 +310,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       int lz2;
       asm volatile("v_mov_b32 %0, 0" : "=v"(lz2));
       const int l31b = l31 + lz2;
-      f32x16 acc2[2];
-      const char* hrow[2];
+      f32x16 acc2[NR2];
+      const char* hrow[NR2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NR2; ++i) {
         const int m = (rb2 + i) * 32 + l31b;
         const int my = (int)(((unsigned)m * inv_pw) >> 16);
         hrow[i] = t1 + (my * HW2 + (m - my * PW)) * TP + 16 * lh;
@@ -300,11 +322,11 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       // in flight (LDS-DMA) during this phase, and while one is pending hipcc treats the LGKM counter as out of order and turns
       // every wait for a compiler-visible ds_read into lgkmcnt(0) -- i.e. it would wait for the reads just issued as well.
       constexpr int D2 = 4;
-      bf16x8 af[D2][2];
+      bf16x8 af[D2][NR2];
       auto p2_read = [&](int k) {  // k-step k = tap * 4 + ks: both row tiles
         const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NR2; ++i) {
           const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(hrow[i] + (kh * HW2 + kw) * TP);
           if (ks == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(af[k % D2][i]) : "v"(ad));
           else if (ks == 1) asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(af[k % D2][i]) : "v"(ad));
@@ -322,23 +344,31 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 #pragma unroll
       for (int k = 0; k < K2; ++k) {
         if (k + D2 - 1 < 36) p2_read(k + D2 - 1);
-        // reads issued after those of k-step k: two per k-step still ahead
-        const int ahead = (k + D2 - 1 < 36 ? D2 - 1 : 35 - k) * 2;
-        if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        // reads issued after those of k-step k: NR2 per k-step still ahead
+        const int ahead = (k + D2 - 1 < 36 ? D2 - 1 : 35 - k) * NR2;
+        if constexpr (NR2 == 2) {
+          if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+          else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+          else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
+        } else {
+          if (ahead == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[k % D2][0]));
+          else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[k % D2][0]));
+          else if (ahead == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[k % D2][0]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[k % D2][0]));
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NR2; ++i) {
           if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
           else BK_MFMA(acc2[i], W2f[k], af[k % D2][i]);
         }
       }
-      BK_MFMA_DRAIN2(acc2[0], acc2[1]);
+      if constexpr (NR2 == 2) BK_MFMA_DRAIN2(acc2[0], acc2[1]);
+      else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc2[0])::"memory");
       BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
       const float* sp = s2 + ct1 * 32 + 4 * lh;  // b2 = s2 + 64
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NR2; ++i) {
         char* wp = t1 + ((rb2 + i) * 32 + l31b) * TP + ct1 * 64 + 8 * lh;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -374,17 +404,17 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
           else BK_MFMA(acc3[0][j], W3f[j][ks], av[0][ks]);
         }
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+      for (int rt = 0; rt < NR3; ++rt) {
         const int cb = rt & 1, nb = cb ^ 1;
         BK_MFMA_DRAIN2(acc3[cb][0], acc3[cb][1]);
-        if (rt + 2 < 4) {  // fragments of tile rt + 2 into the buffer tile rt has just finished with
+        if (rt + 2 < NR3) {  // fragments of tile rt + 2 into the buffer tile rt has just finished with
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) av[cb][ks] = *reinterpret_cast<const bf16x8*>(pbase + (rt + 2) * 32 * TP + ks * 32);
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int j = c >> 2, gq = c & 3;
-          if (rt < 3) {
+          if (rt < NR3 - 1) {
             const int ks2 = c >> 1, j2 = c & 1;
             if (ks2 == 0) BK_MFMA0(acc3[nb][j2], W3f[j2][0], av[nb][0]);
             else BK_MFMA(acc3[nb][j2], W3f[j2][ks2], av[nb][ks2]);
@@ -411,6 +441,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     }
     t = t_next;
     td = td_next;
+    if (DB) xb = xb == smem ? smem + XBB : smem;
   }
 }
 
@@ -701,11 +732,15 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
   }
 }
 
-int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s) {
+// small != 0: the double-buffered 64-position variant (the tile table must hold patches of <= 64 positions with <= 128 halo rows)
+int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
   static bool attr_set = false;
   static int ncu = 256;
+  constexpr int lds_big = 192 * 512 + 192 * TP + (4 * MID + 2 * C) * 4, lds_small = 2 * 128 * 512 + 128 * TP + (4 * MID + 2 * C) * 4;
+  static_assert(lds_big == LDS_BYTES && lds_small <= 160 * 1024, "LDS budget");
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)bottleneck64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
+    if (hipFuncSetAttribute((const void*)bottleneck64_kernel<3, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big) != hipSuccess) return -7;
+    if (hipFuncSetAttribute((const void*)bottleneck64_kernel<2, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small) != hipSuccess) return -7;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -715,7 +750,8 @@ int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s) {
   // the tile walk pairs blockIdx & 7 (XCD) with blockIdx >> 3: the grid must be a whole number of 8-block rounds
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
-  hipLaunchKernelGGL(bottleneck64_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
+  if (small) hipLaunchKernelGGL((bottleneck64_kernel<2, 1, 2, true>), dim3(grid), dim3(256), lds_small, s, a);
+  else hipLaunchKernelGGL((bottleneck64_kernel<3, 2, 4, false>), dim3(grid), dim3(256), lds_big, s, a);
   return (int)hipGetLastError();
 }
 

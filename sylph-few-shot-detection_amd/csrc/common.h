@@ -134,7 +134,7 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
 bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a);
 int launch_conv_hpipe(const ConvArgs& a, hipStream_t s);
 int launch_hpipe_pack_weights(const void* w_igemm, void* w_hpipe, int Cout, int Cin, hipStream_t s);  // a.wt of an hpipe launch
-int launch_bottleneck64(const BottleneckArgs& a, hipStream_t s);   // bottleneck.hip: identity block, persistent, weights in registers
+int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s);   // bottleneck.hip: identity block, persistent, weights in registers; small: 64-position patches, double-buffered halo
 int launch_bottleneck64p(const BottleneckArgs& a, hipStream_t s);  // first block of res2: x [pos][64], w3 = [256][128] packed [W3 | Wsc], y = relu(acc + b3)
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 // conv_pw.hip: persistent pipelined pointwise (1x1) conv, bf16; a.wt = the layer's stage-image weights (launch_pw_pack_weights),
