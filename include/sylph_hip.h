@@ -218,6 +218,12 @@ int sylph_bottleneck(sylph_ctx* ctx, const float* x_nchw_dev, int B, int Cin, in
                      const float* const* w_host, const float* const* scale_host, const float* const* shift_host,
                      float* y_nchw_dev);
 
+/* Kernel parity entry: one FPN lateral as sylph_backbone_fpn launches it (detectron2 FPN.forward: lateral 1x1 conv + bias, plus
+ * the nearest-2x upsampled level above, fused as a residual; call site meta_one_stage_detector.py:181,273).  x (B,C,H,W) fp32 NCHW
+ * device; w_host (256,C,1,1), bias_host (256); top (B,256,H/2,W/2) device or NULL (fpn_lateral5); y (B,256,H,W) fp32 NCHW device. */
+int sylph_fpn_lateral(sylph_ctx* ctx, const float* x_nchw_dev, int B, int C, int H, int W, const float* w_host, const float* bias_host,
+                      const float* top_nchw_dev, float* y_nchw_dev);
+
 /* Bytes of device memory currently held by the context (weights + workspace). */
 int64_t sylph_device_bytes(sylph_ctx* ctx);
 

@@ -2308,6 +2308,45 @@ int sylph_bottleneck(sylph_ctx* c, const float* x, int B, int Cin, int H, int W,
   return 0;
 }
 
+int sylph_fpn_lateral(sylph_ctx* c, const float* x, int B, int C, int H, int W, const float* w_host, const float* bias_host, const float* top,
+                      float* y) {
+  HIPCHK(hipSetDevice(c->device));
+  const int bk = c->dt == DT_BF16 ? 64 : 32;
+  if (C % bk != 0) return fail("sylph_fpn_lateral: Cin must be a multiple of " + std::to_string(bk));
+  if (top && ((H & 1) || (W & 1))) return fail("sylph_fpn_lateral: the top-down input is half the size: H and W must be even");
+  sylph_ctx tmp;  // scratch allocations freed on return
+  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros; tmp.cfg = c->cfg;
+  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
+  HostTensor hw;
+  hw.shape = {256, C, 1, 1};
+  hw.data.assign(w_host, w_host + (size_t)256 * C);
+  ConvLayer L;
+  RET(pack_conv(&tmp, {&hw}, &L));
+  RET(upload_vec(&tmp, &L.shift, std::vector<float>(bias_host, bias_host + 256), L.Cout_pad));
+  const size_t e = tmp.esz();
+  void *xin, *yout, *tp = nullptr;
+  RET(tmp.dalloc(&xin, (size_t)B * H * W * C * e));
+  RET(tmp.dalloc(&yout, (size_t)B * H * W * 256 * e));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_import_nchw(c->dt, x + (size_t)b * C * H * W, xin, C, H * W, b * H * W, C, c->stream), "import");
+  ConvOpts o;
+  std::vector<SegDesc> segs = image_segs(B, H, W, H, W);
+  if (top) {  // exactly the launch build_backbone makes for fpn_lateral3 / 4: residual = nearest 2x upsample of the level above
+    const int h2 = H / 2, w2 = W / 2;
+    RET(tmp.dalloc(&tp, (size_t)B * h2 * w2 * 256 * e));
+    for (int b = 0; b < B; ++b)
+      KCHK(launch_import_nchw(c->dt, top + (size_t)b * 256 * h2 * w2, tp, 256, h2 * w2, b * h2 * w2, 256, c->stream), "import");
+    o.res = tp; o.res_ld = 256; o.res_mode = 2;
+    segs = image_segs(B, H, W, H, W, h2, w2);
+  }
+  std::vector<OpFn> ops;
+  RET(add_conv(&tmp, ops, L, xin, C, yout, 256, segs, o));
+  RET(run_ops(c, ops, "fpn_lateral"));
+  for (int b = 0; b < B; ++b)
+    KCHK(launch_export_nchw(c->dt, yout, y + (size_t)b * 256 * H * W, 256, H * W, b * H * W, 256, c->stream), "export");
+  return 0;
+}
+
 int sylph_group_norm(sylph_ctx* c, const float* x, int B, int H, int W, const float* gamma_host, const float* beta_host,
                      int relu, float* y) {
   HIPCHK(hipSetDevice(c->device));

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "sylph_export_tower": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sylph_bottleneck": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p),
                                  POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    "sylph_fpn_lateral": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sylph_device_bytes": (c_int64, [c_void_p]),
     "sylph_profile_enable": (c_int, [c_void_p, c_int]),
     "sylph_bench_conv": (c_int, [c_void_p] + [c_int] * 12 + [POINTER(c_float), POINTER(ctypes.c_double)]),

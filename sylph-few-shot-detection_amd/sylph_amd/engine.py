@@ -555,6 +555,17 @@ class Engine:
               "bottleneck")
         return y
 
+    def fpn_lateral(self, x, w, bias, top=None):
+        """One FPN lateral (1x1 conv + bias [+ nearest-2x upsampled `top`]) through the backbone's own launch."""
+        self._stream()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, C, H, W = x.shape
+        wh, bh = w.detach().cpu().float().contiguous(), bias.detach().cpu().float().contiguous()
+        tp = top.to(self.device, torch.float32).contiguous() if top is not None else None
+        y = torch.empty(B, 256, H, W, device=self.device)
+        check(self.L.sylph_fpn_lateral(self._ctx, _ptr(x), B, C, H, W, _ptr(wh), _ptr(bh), _ptr(tp), _ptr(y)), "fpn_lateral")
+        return y
+
     def device_bytes(self) -> int:
         return int(self.L.sylph_device_bytes(self._ctx))
 

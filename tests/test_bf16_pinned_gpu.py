@@ -129,6 +129,15 @@ def test_tower_and_prediction_kernels_pinned_on_full_pyramid():
                 _assert_f32(rg[l], reg, f"reg level {l}")
                 _assert_f32(ct[l], ctr, f"ctrness level {l}")
                 _assert_f32(io[l], iou, f"iou level {l}")
+    # many-way episode (LVIS-like, N > 32): the last cls-tower GroupNorm is applied in place (gn_apply_partials_kernel) and the
+    # class-conditional conv runs on conv_igemm with fp32 output -- same operands, same bound
+    ys, cfs = eng.export_tower(0, 3)
+    ys, cfs = [t.cpu() for t in ys], [t.cpu() for t in cfs]
+    many = Wt.synthetic_codes(337, seed=6, scale=2.0)
+    eng.head(many["cls_conv"], many["cls_bias"])
+    lo337 = eng.export_head()[0]
+    for l in range(5):
+        _assert_f32(lo337[l], OB16.cls_logits(OB16.gn_apply(ys[l], cfs[l]), many["cls_conv"], many["cls_bias"]), f"337-way logits level {l}")
 
 
 # ------------------------------------------------------------------------------------------------ single backbone kernels
@@ -166,6 +175,29 @@ def test_bottleneck_blocks_pinned_at_production_shape(case):
     y = eng.bottleneck(x, ws, scales, shifts, stride)
     want = OB16.bottleneck(x, ws, scales, shifts, stride)
     _assert_ulps(y, want, name, max_ulp=2.0, max_frac=0.03, floor="rms")
+
+
+LATERALS = [("fpn_lateral5", 2048, 25, 42, False, 32), ("fpn_lateral4 (+ top-down)", 1024, 50, 84, True, 16),
+            ("fpn_lateral3 (+ top-down)", 512, 100, 168, True, 4)]
+
+
+@pytest.mark.parametrize("case", LATERALS, ids=[c[0].split(" ")[0] for c in LATERALS])
+def test_fpn_laterals_pinned_at_production_shape(case):
+    """conv_pw_kernel<128, 256, 3, RES, false> on the FPN laterals: RES = 0 (lateral5) and RES = 2 (lateral4 / 3: the nearest-2x
+    upsampled level above added as a residual in the epilogue) at their 800x1344 map sizes, batches large enough for the production
+    kernel selection; one conv, no bf16 intermediate: <= 1 ulp."""
+    from oracle import bf16 as OB16
+    name, cin, h, w, has_top, B = case
+    g = torch.Generator().manual_seed(cin)
+    x = OB16.r(F.relu(torch.randn(B, cin, h, w, generator=g)))
+    wt = torch.randn(256, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    bias = 0.2 * torch.randn(256, generator=g)
+    top = OB16.r(torch.randn(B, 256, h // 2, w // 2, generator=g)) if has_top else None
+    eng = _engine("bf16")
+    y = eng.fpn_lateral(x, wt, bias, top)
+    res = F.interpolate(top, scale_factor=2.0, mode="nearest") if has_top else None
+    _, want = OB16.conv_epilogue(x, wt, None, bias, res_bf=res)
+    _assert_ulps(y, want, name)
 
 
 def test_stem_pool_kernel_pinned_at_800x1344():

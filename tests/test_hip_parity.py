@@ -734,3 +734,32 @@ def test_codegen_weight_and_scale_layers_match_reference_golden(golden_dir, g3, 
     normed = eng.normalize_codes(code.reshape(1, 257).clone().contiguous(), wn).cpu().numpy()
     np.testing.assert_allclose(normed[0, :256], g[f"norm{i}_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
     np.testing.assert_allclose(normed[0, 256], g[f"norm{i}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
+
+
+def test_c4_support_path_r101_full_size_bf16():
+    """BASELINE config C4 support path at full size: R-101 backbone, LVIS code-generator settings (BIAS_L2_NORM), two classes x 3
+    support images of 800x1333 in ONE batch (sylph_codegen_classes), bf16, against the fp32 CPU oracle: cosine of the un-normalised
+    and of the normalised 256-d codes, bias within 5e-2; and against the one-class-per-call path of the same engine."""
+    from oracle import codegen as CG, episode as E
+    from sylph_amd import synthetic as W
+    sd = W.synthetic_state_dict(0, depth=101)
+    eng = _engine("bf16", _cfg(True, **{"MODEL.RESNETS.DEPTH": 101}))
+    eng.load_state_dict(sd)
+    S, ncls = 3, 2
+    sup = W.synthetic_images(S * ncls, 800, 1333, seed=71)
+    boxes = W.synthetic_boxes(S * ncls, 800, 1333, seed=72)
+    eng.preprocess(sup)
+    eng.backbone()
+    codes = eng.codegen_classes(boxes, S).clone()
+    for k in range(ncls):
+        eng.preprocess(sup[k * S:(k + 1) * S])
+        eng.backbone()
+        one = eng.codegen(boxes[k * S:(k + 1) * S])
+        assert float((one[:256] - codes[k, :256]).abs().max()) <= 2e-2 * float(one[:256].abs().max())
+    ref = E.forward_class_code(sup[:S], boxes[:S], sd, depth=101, bias_l2_norm=True)
+    cos = F.cosine_similarity(codes[0, :256].float().cpu(), ref["cls_conv"].reshape(-1), dim=0).item()
+    assert cos > 0.99, cos
+    normed = eng.normalize_codes(codes[:1].clone().contiguous()).cpu()
+    rc, rb = CG.normalize_code(ref["cls_conv"], ref["cls_bias"], sd)
+    assert F.cosine_similarity(normed[0, :256], rc.reshape(-1), dim=0).item() > 0.99
+    assert abs(normed[0, 256].item() - rb.item()) < 5e-2
