@@ -46,7 +46,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 namespace {
-constexpr int PW_NT = 256;
 
 #define PW_FENCE __builtin_amdgcn_sched_barrier(0)
 #define PW_BAR()                        \
@@ -81,11 +80,15 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 constexpr int pw_lds_bytes(int BM, int BN, int NST) { return NST * (BM + BN) * 64 + 2 * (2 * BN * 4); }
 }  // namespace
 
-// BM x BN tile, NST ring stages, RES: 0 none / 1 residual of the output geometry / 2 nearest-2x upsampled residual, RELU
-template <int BM, int BN, int NST, int RES, bool RELU>
-__global__ __launch_bounds__(PW_NT, 2) void conv_pw_kernel(const ConvArgs a) {
-  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
-  constexpr int AR = BM / 64, BR = BN / 64;  // LDS-DMA instructions per lane and phase for A / W
+// BM x BN tile, NW waves (4: two blocks per CU; 8: the 256 x 256 tile, one block per CU), NST ring stages, RES: 0 none / 1 residual
+// of the output geometry / 2 nearest-2x upsampled residual, RELU
+template <int BM, int BN, int NW, int NST, int RES, bool RELU>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_pw_kernel(const ConvArgs a) {
+  constexpr int NT = NW * 64, WGN = NW / 2;   // waves as 2 (M) x WGN (N)
+  constexpr int WTM = BM / 2, WTN = BN / WGN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPI = NT / 4;                 // rows one block-wide LDS-DMA instruction lands (64-byte rows, 16 bytes per lane)
+  constexpr int AR = BM / RPI, BR = BN / RPI; // LDS-DMA instructions per lane and phase for A / W
+  constexpr int IB = RPI * 64;                // bytes of one block-wide instruction
   constexpr int NLOAD = AR + BR;             // per lane and phase; phase 0 of a tile: + 1 (scale / shift table)
   constexpr int STAGE = (BM + BN) * 64, RING = NST * STAGE, TAB = 2 * BN * 4;
   constexpr int ASZ = BM * 64;
@@ -96,12 +99,12 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_pw_kernel(const ConvArgs a) {
   // of the tile and has landed long before the epilogue; large tiles fetch it chunk by chunk inside the epilogue
   constexpr bool HOIST = RES != 0 && TM * TN * 4 <= 16;
   constexpr int NRES = HOIST ? TM * TN * 4 : 0;
-  static_assert(TM * TN >= 4 && 4 * 4096 <= STAGE && NST >= 3, "tile shape");
+  static_assert(TM * TN >= 4 && NW * 4096 <= STAGE && NST >= 3 && WTN % 64 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int r4 = tid >> 2, s4 = tid & 3;
 
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_pw_kernel(const ConvArgs a) {
     const bool direct1 = a.stride == 1 && in_W == out_W, direct2 = a.stride2 == 1 && in2_W == out_W;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      int pos = row0 + r4 + 64 * i;
+      int pos = row0 + r4 + RPI * i;
       pos = pos < seg_rows ? pos : seg_rows - 1;  // rows past the segment: re-read its last row (their results are discarded)
       const int cl = s4 ^ ((r4 >> 2) & 3);       // source-side swizzle: LDS slot s4 of row r holds logical chunk cl
       int oy = 0, ox = 0;
@@ -164,12 +167,12 @@ __global__ __launch_bounds__(PW_NT, 2) void conv_pw_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const unsigned off = second ? ld_off2[i] : ld_off1[i];
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(dA + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(dA + i * IB), 16, 0, 0);
     }
     const char* wsrc = reinterpret_cast<const char*>(a.wt) + ((size_t)ld_nt * nk + kp) * (size_t)(BN * 64);
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc + j * 4096 + wvo), (lds_ptr_t)(dB + j * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wsrc + j * IB + wvo), (lds_ptr_t)(dB + j * IB), 16, 0, 0);
     int n = NLOAD;
     if (ld_q == 0) {  // scale | shift of the tile's N block -> table slot ld_par (TAB bytes; every wave copies a 1-KiB piece of it)
       const int piece = (wave * 1024) % TAB;
@@ -398,12 +401,14 @@ int launch_pw_pack_weights(const void* w, void* out, int Cout, int K, int BN, hi
 // ratio of conv_hpipe (12 fragment reads per 16 MFMAs) and 6 LDS-DMA instructions per wave and phase.  The 128 x 128 / 4-stage
 // variant (whole residual tile prefetched at the tile start, three activation phases in flight) is kept for A/B runs
 // (SYLPH_PW_TILE=1): measured 5-25 % slower on every layer of the R-50 graph -- per 32-channel phase a wave pays one barrier,
-// one counted wait and its LDS-DMA issue slots (~100 cycles each) for only 8 MFMAs.
+// one counted wait and its LDS-DMA issue slots (~100 cycles each) for only 8 MFMAs.  SYLPH_PW_TILE=3: 256 x 256 tile, 8 lock-step
+// waves, one block per CU (A/B only: equal to the default within 3 %).
 bool conv_pw_tile(int cout, int k_total, bool has_res, int* BM, int* BN) {
   static const int force = getenv("SYLPH_PW_TILE") ? atoi(getenv("SYLPH_PW_TILE")) : 0;
   if (cout % 128 != 0) return false;
   (void)k_total; (void)has_res;
   const bool large = force != 1;
+  if (force == 3 && cout % 256 == 0) { *BM = 256; *BN = 256; return true; }  // experiment: 256 x 256 tile, 8 waves, one block per CU
   if (large) { *BN = cout % 256 == 0 ? 256 : 128; *BM = 384 - *BN; }
   else { *BM = 128; *BN = 128; }
   return true;
@@ -417,7 +422,7 @@ bool conv_pw_ok(DType dt, bool out_f32, const ConvArgs& a) {
          a.trash != nullptr && a.pw_desc != nullptr && a.pw_table != nullptr;
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int NW = 4>
 static int launch_pw_t(const ConvArgs& a, int grid, hipStream_t s) {
   const bool relu = a.relu_nch > 0;
   constexpr int lds = pw_lds_bytes(BM, BN, NST);
@@ -425,10 +430,10 @@ static int launch_pw_t(const ConvArgs& a, int grid, hipStream_t s) {
   do {                                                                                                                             \
     static bool attr = false;                                                                                                      \
     if (!attr) {                                                                                                                   \
-      if (hipFuncSetAttribute((const void*)conv_pw_kernel<BM, BN, NST, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -7; \
+      if (hipFuncSetAttribute((const void*)conv_pw_kernel<BM, BN, NW, NST, R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -7; \
       attr = true;                                                                                                                 \
     }                                                                                                                              \
-    hipLaunchKernelGGL((conv_pw_kernel<BM, BN, NST, R, L>), dim3(grid), dim3(PW_NT), lds, s, a);                                   \
+    hipLaunchKernelGGL((conv_pw_kernel<BM, BN, NW, NST, R, L>), dim3(grid), dim3(NW * 64), lds, s, a);                                   \
     return (int)hipGetLastError();                                                                                                 \
   } while (0)
   if (a.res_mode == 0) { if (relu) PW_GO(0, true); else PW_GO(0, false); }
@@ -458,6 +463,11 @@ int launch_conv_pw(const ConvArgs& a_in, int BM, int BN, hipStream_t s) {
   if (BM == 128 && BN == 128) {
     if (nst == 3) { grid = (int)((3L * n_cu + 7) & ~7L); if (need < grid) grid = (int)need; return launch_pw_t<128, 128, 3>(a, grid, s); }
     return launch_pw_t<128, 128, 4>(a, grid, s);
+  }
+  if (BM == 256 && BN == 256) {  // 8 waves, one block per CU
+    grid = (n_cu + 7) & ~7;
+    if (need < grid) grid = (int)need;
+    return launch_pw_t<256, 256, 3, 8>(a, grid, s);
   }
   if (BM == 128 && BN == 256) return launch_pw_t<128, 256, 3>(a, grid, s);
   if (BM == 256 && BN == 128) return launch_pw_t<256, 128, 3>(a, grid, s);

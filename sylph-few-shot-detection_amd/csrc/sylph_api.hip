@@ -710,7 +710,7 @@ static int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, co
     a.pw_table = it->second.second;
     if (!c->pw_trash) {
       OwnerScope ctx_owned(c, nullptr);
-      RET(c->dalloc(&c->pw_trash, 4096));
+      RET(c->dalloc(&c->pw_trash, 8192));
     }
     a.trash = c->pw_trash;
     std::vector<PwDesc> pd;
