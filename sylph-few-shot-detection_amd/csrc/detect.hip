@@ -31,8 +31,26 @@ __device__ __forceinline__ float quality_of(const float* pred_row, int mode) {
   return sqrtf(sigmoid_f(pred_row[5]) * sigmoid_f(pred_row[4]));
 }
 
-constexpr int SCAN_ROWS = 64;
+__device__ __forceinline__ float quality_from(float ctr_logit, float iou_logit, int mode) {  // = quality_of on loaded values
+  if (mode == 0) return sigmoid_f(ctr_logit);
+  if (mode == 1) return sigmoid_f(iou_logit);
+  return sqrtf(sigmoid_f(iou_logit) * sigmoid_f(ctr_logit));
+}
 
+constexpr int SCAN_ROWS = 64;
+constexpr int SCAN_UNROLL = 4;    // loads in flight per thread (16 B each on the vector path)
+constexpr int SCAN_STAGE = 2048;  // candidates a block collects in LDS before it reserves a range of the (image, level) buffer
+
+// Candidates are appended per (image, level).  One global atomicAdd per CANDIDATE on that one counter serialises: at 866 classes
+// (LVIS) and a few per cent of the 14.5 M scores of a P3 level above the threshold the scan took 32 ms for 16 images.  Here a
+// block collects its candidates in LDS (wave-aggregated LDS atomics: one per wave and iteration) and reserves global ranges with
+// one atomicAdd per flush -- a handful per block.  The order of the buffer is irrelevant: selection and sort work on the
+// composite (score, ~ordinal) keys.  The logits are the only HBM traffic that matters (4 bytes per score); a thread keeps
+// SCAN_UNROLL 16-byte loads in flight before it looks at any of them (W = 4 classes per load; W = 1 if the row pitch is odd).
+// The LDS list is sized for occupancy (16 KiB: 8 blocks per CU), not for the worst case: it is flushed once half full, and
+// the part of a wave's candidates that still does not fit (density above ~50 % of a round) is appended directly with one
+// global atomicAdd per wave.
+template <int W>
 __global__ __launch_bounds__(256) void decode_scan_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
                                                           const float* __restrict__ logits,
                                                           const float* __restrict__ pred, int pred_ld,
@@ -43,88 +61,356 @@ __global__ __launch_bounds__(256) void decode_scan_kernel(const DecodeCfg cfg, c
   if (r_begin >= sg.nloc) return;
   const int r_end = min(sg.nloc, r_begin + SCAN_ROWS);
   const int N = cfg.num_classes;
-  const int total = (r_end - r_begin) * N;
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int r = e / N, c = e - r * N;
-    const int loc = r_begin + r;
-    const size_t row = (size_t)sg.row0 + loc;
-    float p = sigmoid_f(logits[row * cfg.logits_ld + c]);
-    float s;
-    bool pass;
-    if (cfg.thresh_with_ctr) {
-      p = p * quality_of(pred + row * pred_ld, cfg.quality_mode);
-      pass = p > cfg.pre_nms_thresh;
-      s = p;
-    } else {
-      pass = p > cfg.pre_nms_thresh;
-      s = pass ? p * quality_of(pred + row * pred_ld, cfg.quality_mode) : 0.f;
+  const int G = (N + W - 1) / W;  // W-wide class groups per location
+  const int total = (r_end - r_begin) * G;
+  __shared__ unsigned s_key[SCAN_STAGE], s_idx[SCAN_STAGE];
+  __shared__ unsigned s_n, s_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_n = 0u;
+  __syncthreads();
+  auto flush = [&]() {  // block-uniform
+    __syncthreads();
+    const unsigned n = min(s_n, (unsigned)SCAN_STAGE);
+    if (n > 0u) {
+      if (tid == 0) s_base = atomicAdd(&buf.cand_count[seg], n);
+      __syncthreads();
+      const unsigned base = s_base;
+      for (unsigned i = tid; i < n; i += 256) {
+        const unsigned pos = base + i;
+        if (pos < (unsigned)cfg.cand_cap) {
+          buf.cand_key[(size_t)seg * cfg.cand_cap + pos] = s_key[i];
+          buf.cand_idx[(size_t)seg * cfg.cand_cap + pos] = s_idx[i];
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s_n = 0u;
+      __syncthreads();
     }
-    if (pass) {
-      const unsigned pos = atomicAdd(&buf.cand_count[seg], 1u);
-      if (pos < (unsigned)cfg.cand_cap) {
-        buf.cand_key[(size_t)seg * cfg.cand_cap + pos] = __float_as_uint(s);
-        buf.cand_idx[(size_t)seg * cfg.cand_cap + pos] = (unsigned)(loc * N + c);
+  };
+  // (location, group) of the thread's element without a division per element: it advances by (256 / G, 256 % G) per step
+  const int step_r = 256 / G, step_g = 256 - step_r * G;
+  int r = tid / G, g = tid - r * G;
+  const int iters = (total + 255) / 256;
+  // sigmoid(x) > thr needs x > logit(thr) (and so does sigmoid(x) * quality > thr, quality <= 1): scores whose logit is below
+  // that bound by more than 1e-2 -- five orders of magnitude above the rounding error of either form -- skip the exp and the
+  // division, which is ~95 % of a many-way level.  The exact fp32 test on the sigmoid still decides everything near the bound.
+  const float thr = cfg.pre_nms_thresh;
+  const float x_min = (thr > 0.f && thr < 1.f) ? logf(thr / (1.f - thr)) - 1e-2f : (thr >= 1.f ? INFINITY : -INFINITY);
+  for (int it0 = 0; it0 < iters; it0 += SCAN_UNROLL) {
+    if (it0 > 0) {
+      __syncthreads();
+      const unsigned n_now = s_n;
+      __syncthreads();  // every thread has read the same value before any wave appends again: block-uniform decision
+      if (n_now > (unsigned)(SCAN_STAGE / 2)) flush();
+    }
+    float x[SCAN_UNROLL][W], qa[SCAN_UNROLL], qb[SCAN_UNROLL];
+    int loc_u[SCAN_UNROLL], c_u[SCAN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SCAN_UNROLL; ++u) {
+      const int e = (it0 + u) * 256 + tid;
+      loc_u[u] = r_begin + r;
+      c_u[u] = e < total ? g * W : N;  // N: nothing of this slot is a class
+      if (e < total) {
+        const float* src = logits + ((size_t)sg.row0 + loc_u[u]) * cfg.logits_ld + g * W;
+        // the location's centerness / IoU logits ride along (a cache hit for all but the first group of a location): a
+        // dependent load after the threshold test would stall every round on HBM latency
+        const float* prow = pred + ((size_t)sg.row0 + loc_u[u]) * pred_ld;
+        qa[u] = cfg.quality_mode != 1 ? prow[4] : 0.f;
+        qb[u] = cfg.quality_mode != 0 ? prow[5] : 0.f;
+        if constexpr (W == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
+        } else {
+          x[u][0] = src[0];
+        }
+      }
+      r += step_r; g += step_g;
+      if (g >= G) { g -= G; ++r; }
+    }
+#pragma unroll
+    for (int u = 0; u < SCAN_UNROLL; ++u) {
+      bool pass[W];
+      float sc[W];
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        pass[w] = false; sc[w] = 0.f;
+        if (c_u[u] + w < N) {
+          const float p = x[u][w] > x_min ? sigmoid_f(x[u][w]) : 0.f;
+          if (p > thr) { sc[w] = p; pass[w] = true; any = true; }
+        }
+      }
+      if (any) {  // the quality (centerness / IoU) of the location: p * quality <= p, so it is only needed above the threshold
+        const float q = quality_from(qa[u], qb[u], cfg.quality_mode);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const float pq = sc[w] * q;
+          if (cfg.thresh_with_ctr) pass[w] = pass[w] && pq > thr;
+          sc[w] = pq;
+        }
+      }
+      unsigned long long m[W];
+      unsigned cnt = 0u;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { m[w] = __ballot(pass[w]); cnt += (unsigned)__popcll(m[w]); }
+      if (cnt != 0u) {  // wave-uniform
+        unsigned wbase = 0u;
+        if (lane == 0) wbase = atomicAdd(&s_n, cnt);
+        wbase = __shfl(wbase, 0);
+        // positions [wbase, wbase + cnt): those below SCAN_STAGE are LDS slots, the rest one reserved global range
+        const unsigned first_over = max(wbase, (unsigned)SCAN_STAGE);
+        unsigned gbase = 0u;
+        if (wbase + cnt > first_over) {  // wave-uniform
+          if (lane == 0) gbase = atomicAdd(&buf.cand_count[seg], wbase + cnt - first_over);
+          gbase = __shfl(gbase, 0);
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          if (pass[w]) {
+            const unsigned pos = wbase + (unsigned)__popcll(m[w] & below);
+            const unsigned kb = __float_as_uint(sc[w]), ix = (unsigned)(loc_u[u] * N + c_u[u] + w);
+            if (pos < (unsigned)SCAN_STAGE) {
+              s_key[pos] = kb;
+              s_idx[pos] = ix;
+            } else {
+              const unsigned gpos = gbase + (pos - first_over);
+              if (gpos < (unsigned)cfg.cand_cap) {
+                buf.cand_key[(size_t)seg * cfg.cand_cap + gpos] = kb;
+                buf.cand_idx[(size_t)seg * cfg.cand_cap + gpos] = ix;
+              }
+            }
+          }
+          wbase += (unsigned)__popcll(m[w]);
+        }
       }
     }
   }
+  flush();
 }
 
-__global__ __launch_bounds__(1024) void decode_select_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
-                                                             const DecodeBuffers buf) {
-  const int seg = blockIdx.x, tid = threadIdx.x;
-  const DecodeSeg sg = segs[seg];
-  unsigned n = buf.cand_count[seg];
-  if (n > (unsigned)cfg.cand_cap) {
-    if (tid == 0) atomicOr(buf.status, 1);
-    n = cfg.cand_cap;
+constexpr int SEL_UNROLL = 8;   // key loads in flight per thread
+
+__device__ __forceinline__ unsigned sel_bin_of(unsigned kbits) { return min(kbits >> 19, (unsigned)(SEL_BINS - 1)); }
+
+__device__ __forceinline__ unsigned long long pool_composite(const DecodeCfg& cfg, const DecodeSeg& sg, unsigned kbits, unsigned ix) {
+  const float sq = sqrtf(__uint_as_float(kbits));
+  const unsigned ord = sg.loc_base * (unsigned)cfg.num_classes + ix;
+  return ((unsigned long long)__float_as_uint(sq) << 32) | (unsigned long long)(~ord);
+}
+
+// Block-level append to a global list with ONE atomicAdd on its counter per block: returning atomics on one address take
+// ~80 ns each at L2, and the five levels of an image share pool_count[image] (5000 appends = 0.4 ms when done one by one).
+// Entries collect in LDS; the few that do not fit (cap < entries of this block) are appended directly.
+template <int CAP>
+struct StagedAppend {
+  unsigned long long* buf;  // LDS [CAP]
+  unsigned* cnt;            // LDS
+  unsigned* base;           // LDS
+  unsigned* g_count;
+  unsigned long long* g_dst;
+  unsigned g_cap;
+  __device__ __forceinline__ void init() { if (threadIdx.x == 0) *cnt = 0u; }  // followed by a __syncthreads() of the caller
+  __device__ __forceinline__ void push(unsigned long long v) {
+    const unsigned pos = atomicAdd(cnt, 1u);
+    if (pos < (unsigned)CAP) { buf[pos] = v; return; }
+    const unsigned gpos = atomicAdd(g_count, 1u);
+    if (gpos < g_cap) g_dst[gpos] = v;
   }
+  __device__ __forceinline__ void flush() {  // block-uniform
+    __syncthreads();
+    const unsigned n = min(*cnt, (unsigned)CAP);
+    if (n == 0u) return;
+    if (threadIdx.x == 0) *base = atomicAdd(g_count, n);
+    __syncthreads();
+    const unsigned b = *base;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+      if (b + i < g_cap) g_dst[b + i] = buf[i];
+  }
+};
+
+// exact radix select (8 bits per pass, most significant first) of the `remain`-th largest of the composites load(i), i < n;
+// every thread of the 1024-thread block calls it and gets the threshold composite
+template <typename Load>
+__device__ __forceinline__ unsigned long long radix_select_desc(unsigned n, unsigned remain, unsigned* hist,
+                                                                unsigned long long* sh_prefix, unsigned* sh_remain,
+                                                                Load load) {
+  const int tid = threadIdx.x;
+  unsigned long long prefix = 0ull;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned long long hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+    for (unsigned i = tid; i < n; i += 1024) {
+      const unsigned long long comp = load(i);
+      if ((comp & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(comp >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned cum = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (cum + hist[d] >= remain) break;
+        cum += hist[d];
+      }
+      *sh_prefix = prefix | ((unsigned long long)d << shift);
+      *sh_remain = remain - cum;
+    }
+    __syncthreads();
+    prefix = *sh_prefix;
+    remain = *sh_remain;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// Pre-NMS top-k per (image, level): keep exactly the k largest (score, lower index first) of more than k candidates.
+// A many-way level holds ~10^6 candidates (866 classes x 16 800 locations x a few per cent), so the k-th largest is located
+// in two reads of the scores instead of eight of scores and indices, by `parts` blocks per level:
+//   hist      : 4096-bin histogram of the score's exponent and top mantissa bits (block-local in LDS, merged with atomics)
+//   partition : the bin b* the k-th largest falls in is read off the histogram; candidates of higher bins go to the pool
+//               outright, the boundary bin's (a few hundred) to a per-level list
+//   finish    : exact radix select of the list; a boundary bin too full for the list (scores piled on one value) is the one
+//               case nothing was partitioned and the radix select runs over the whole buffer.
+// Levels with at most k candidates skip hist and finish; partition copies them to the pool.
+__device__ __forceinline__ unsigned sel_count(const DecodeCfg& cfg, const DecodeBuffers& buf, int seg) {
+  const unsigned n = buf.cand_count[seg];
+  return n > (unsigned)cfg.cand_cap ? (unsigned)cfg.cand_cap : n;
+}
+
+__global__ __launch_bounds__(1024) void decode_hist_kernel(const DecodeCfg cfg, const DecodeBuffers buf) {
+  const int seg = blockIdx.y, tid = threadIdx.x;
+  const unsigned n = sel_count(cfg, buf, seg);
+  if (n <= (unsigned)cfg.pre_nms_topk) return;
+  const unsigned slice = (n + gridDim.x - 1) / gridDim.x;
+  const unsigned i_begin = blockIdx.x * slice, i_end = min(n, i_begin + slice);
+  const unsigned* key = buf.cand_key + (size_t)seg * cfg.cand_cap;
+  __shared__ unsigned hist[SEL_BINS];
+  for (int i = tid; i < SEL_BINS; i += 1024) hist[i] = 0u;
+  __syncthreads();
+  for (unsigned i0 = i_begin + tid; i0 < i_end; i0 += 1024 * SEL_UNROLL) {
+    unsigned kb[SEL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SEL_UNROLL; ++u) kb[u] = i0 + u * 1024 < i_end ? key[i0 + u * 1024] : 0u;
+#pragma unroll
+    for (int u = 0; u < SEL_UNROLL; ++u)
+      if (i0 + u * 1024 < i_end) atomicAdd(&hist[sel_bin_of(kb[u])], 1u);
+  }
+  __syncthreads();
+  unsigned* ghist = buf.sel_ws + (size_t)seg * SEL_WS;
+  for (int i = tid; i < SEL_BINS; i += 1024)
+    if (hist[i] != 0u) atomicAdd(&ghist[i], hist[i]);
+}
+
+__global__ __launch_bounds__(1024) void decode_partition_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
+                                                                const DecodeBuffers buf) {
+  const int seg = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const DecodeSeg sg = segs[seg];
+  if (blockIdx.x == 0 && tid == 0 && buf.cand_count[seg] > (unsigned)cfg.cand_cap) atomicOr(buf.status, 1);
+  const unsigned n = sel_count(cfg, buf, seg);
+  const unsigned k = (unsigned)cfg.pre_nms_topk;
+  const unsigned slice = (n + gridDim.x - 1) / gridDim.x;
+  const unsigned i_begin = blockIdx.x * slice, i_end = min(n, i_begin + slice);
   const unsigned* key = buf.cand_key + (size_t)seg * cfg.cand_cap;
   const unsigned* idx = buf.cand_idx + (size_t)seg * cfg.cand_cap;
+  unsigned* ghist = buf.sel_ws + (size_t)seg * SEL_WS;
+  unsigned* state = ghist + SEL_BINS;
+  __shared__ unsigned hist[SEL_BINS];
+  __shared__ unsigned sh_bin, sh_need;
+  __shared__ unsigned long long pool_stage[2048], tie_stage[1024];
+  __shared__ unsigned pool_n, pool_base, tie_n, tie_base;
+  StagedAppend<2048> pool{pool_stage, &pool_n, &pool_base, &buf.pool_count[sg.image],
+                          buf.pool_key + (size_t)sg.image * cfg.pool_cap, (unsigned)cfg.pool_cap};
+  StagedAppend<1024> ties{tie_stage, &tie_n, &tie_base, &state[0], buf.sel_tie + (size_t)seg * SEL_TIE, (unsigned)SEL_TIE};
+  pool.init();
+  ties.init();
+  if (n <= k) {
+    __syncthreads();
+    for (unsigned i = i_begin + tid; i < i_end; i += 1024) pool.push(pool_composite(cfg, sg, key[i], idx[i]));
+    pool.flush();
+    return;
+  }
+  for (int i = tid; i < SEL_BINS; i += 1024) hist[i] = ghist[i];
+  __syncthreads();
+  if (tid < 64) {
+    // lane c owns bins [64c, 64c+64); the rotated order keeps the 64 lanes on 64 different LDS banks
+    unsigned sum = 0u;
+    for (int j = 0; j < 64; ++j) sum += hist[lane * 64 + ((j + lane) & 63)];
+    unsigned above = 0u;  // candidates in the chunks above this lane's
+    for (int c = 0; c < 64; ++c) {
+      const unsigned v = __shfl(sum, c);
+      if (c > lane) above += v;
+    }
+    if (above < k && above + sum >= k) {  // exactly one lane: the chunk that holds the k-th largest
+      int b = lane * 64 + 63;
+      for (;; --b) {
+        if (above + hist[b] >= k) break;
+        above += hist[b];
+      }
+      sh_bin = (unsigned)b;
+      sh_need = k - above;  // how many of bin b's candidates are kept
+    }
+  }
+  __syncthreads();
+  const unsigned b_star = sh_bin, n_b = hist[b_star];
+  if (blockIdx.x == 0 && tid == 0) { state[1] = b_star; state[2] = sh_need; state[3] = n_b; }
+  if (n_b > (unsigned)SEL_TIE) return;  // finish selects over the whole buffer
+  for (unsigned i0 = i_begin + tid; i0 < i_end; i0 += 1024 * SEL_UNROLL) {
+    unsigned kb[SEL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SEL_UNROLL; ++u) kb[u] = i0 + u * 1024 < i_end ? key[i0 + u * 1024] : 0u;
+#pragma unroll
+    for (int u = 0; u < SEL_UNROLL; ++u) {
+      const unsigned i = i0 + u * 1024;
+      const unsigned b = sel_bin_of(kb[u]);
+      if (i >= i_end || b < b_star) continue;  // the indices of the (vast) rest are never read
+      const unsigned ix = idx[i];
+      if (b > b_star) pool.push(pool_composite(cfg, sg, kb[u], ix));
+      else ties.push(((unsigned long long)kb[u] << 32) | (unsigned long long)(~ix));
+    }
+  }
+  pool.flush();
+  ties.flush();
+}
+
+__global__ __launch_bounds__(1024) void decode_finish_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
+                                                             const DecodeBuffers buf) {
+  const int seg = blockIdx.x, tid = threadIdx.x;
+  const unsigned n = sel_count(cfg, buf, seg);
   const unsigned k = (unsigned)cfg.pre_nms_topk;
+  if (n <= k) return;
+  const DecodeSeg sg = segs[seg];
+  const unsigned* state = buf.sel_ws + (size_t)seg * SEL_WS + SEL_BINS;
+  const unsigned need = state[2], n_b = state[3];
   __shared__ unsigned hist[256];
   __shared__ unsigned long long sh_prefix;
   __shared__ unsigned sh_remain;
-  unsigned long long thresh = 0ull;
-  if (n > k) {
-    unsigned long long prefix = 0ull;
-    unsigned remain = k;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-      if (tid < 256) hist[tid] = 0u;
-      __syncthreads();
-      const unsigned long long hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
-      for (unsigned i = tid; i < n; i += 1024) {
-        const unsigned long long comp = ((unsigned long long)key[i] << 32) | (unsigned long long)(~idx[i]);
-        if ((comp & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(comp >> shift) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        unsigned cum = 0;
-        int d = 255;
-        for (; d > 0; --d) {
-          if (cum + hist[d] >= remain) break;
-          cum += hist[d];
-        }
-        sh_prefix = prefix | ((unsigned long long)d << shift);
-        sh_remain = remain - cum;
-      }
-      __syncthreads();
-      prefix = sh_prefix;
-      remain = sh_remain;
+  __shared__ unsigned long long pool_stage[2048];
+  __shared__ unsigned pool_n, pool_base;
+  StagedAppend<2048> pool{pool_stage, &pool_n, &pool_base, &buf.pool_count[sg.image],
+                          buf.pool_key + (size_t)sg.image * cfg.pool_cap, (unsigned)cfg.pool_cap};
+  pool.init();
+  __syncthreads();
+  if (n_b <= (unsigned)SEL_TIE) {
+    const unsigned long long* tie = buf.sel_tie + (size_t)seg * SEL_TIE;
+    const unsigned long long thresh =
+        need >= n_b ? 0ull : radix_select_desc(n_b, need, hist, &sh_prefix, &sh_remain, [&](unsigned i) { return tie[i]; });
+    for (unsigned i = tid; i < n_b; i += 1024) {
+      const unsigned long long comp = tie[i];
+      if (comp >= thresh) pool.push(pool_composite(cfg, sg, (unsigned)(comp >> 32), ~(unsigned)(comp & 0xffffffffull)));
     }
-    thresh = prefix;
-  }
-  const int img = sg.image;
-  for (unsigned i = tid; i < n; i += 1024) {
-    const unsigned long long comp = ((unsigned long long)key[i] << 32) | (unsigned long long)(~idx[i]);
-    if (comp >= thresh) {
-      const float sq = sqrtf(__uint_as_float(key[i]));
-      const unsigned ord = sg.loc_base * (unsigned)cfg.num_classes + idx[i];
-      const unsigned pos = atomicAdd(&buf.pool_count[img], 1u);
-      if (pos < (unsigned)cfg.pool_cap)
-        buf.pool_key[(size_t)img * cfg.pool_cap + pos] =
-            ((unsigned long long)__float_as_uint(sq) << 32) | (unsigned long long)(~ord);
+  } else {
+    const unsigned* key = buf.cand_key + (size_t)seg * cfg.cand_cap;
+    const unsigned* idx = buf.cand_idx + (size_t)seg * cfg.cand_cap;
+    const unsigned long long thresh = radix_select_desc(n, k, hist, &sh_prefix, &sh_remain, [&](unsigned i) {
+      return ((unsigned long long)key[i] << 32) | (unsigned long long)(~idx[i]);
+    });
+    for (unsigned i = tid; i < n; i += 1024) {
+      const unsigned long long comp = ((unsigned long long)key[i] << 32) | (unsigned long long)(~idx[i]);
+      if (comp >= thresh) pool.push(pool_composite(cfg, sg, key[i], idx[i]));
     }
   }
+  pool.flush();
 }
 
 // per image: bitonic sort (descending) of the pool keys in LDS, then decode the sorted candidates
@@ -328,8 +614,18 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   (void)hipMemsetAsync(buf.pool_count, 0, sizeof(unsigned) * B, s);
   (void)hipMemsetAsync(buf.status, 0, sizeof(int), s);
   dim3 g1((max_nloc + SCAN_ROWS - 1) / SCAN_ROWS, nseg);
-  hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
-  hipLaunchKernelGGL(decode_select_kernel, dim3(nseg), dim3(1024), 0, s, cfg, segs_dev, buf);
+  if ((cfg.logits_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0)
+    hipLaunchKernelGGL(decode_scan_kernel<4>, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
+  else
+    hipLaunchKernelGGL(decode_scan_kernel<1>, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
+  // blocks per level of the selection: one per 64 Ki candidate slots, so a few-way plan (84 000 slots) runs 2 and an
+  // 866-way plan (1.8 M slots) 28
+  int parts = (cfg.cand_cap + 65535) / 65536;
+  parts = parts < 1 ? 1 : (parts > 32 ? 32 : parts);
+  (void)hipMemsetAsync(buf.sel_ws, 0, sizeof(unsigned) * (size_t)nseg * SEL_WS, s);
+  hipLaunchKernelGGL(decode_hist_kernel, dim3(parts, nseg), dim3(1024), 0, s, cfg, buf);
+  hipLaunchKernelGGL(decode_partition_kernel, dim3(parts, nseg), dim3(1024), 0, s, cfg, segs_dev, buf);
+  hipLaunchKernelGGL(decode_finish_kernel, dim3(nseg), dim3(1024), 0, s, cfg, segs_dev, buf);
   hipLaunchKernelGGL(decode_sort_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * cfg.pool_cap, s, cfg,
                      segs_dev, pred, pred_ld, buf);
   if (cfg.nms_thresh > 0.f) {

@@ -40,11 +40,20 @@ struct DecodeCfg {
   int max_out;         // per-image output capacity
 };
 
+// pre-NMS top-k workspace (detect.hip)
+constexpr int SEL_BINS = 4096;  // key >> 19 of a non-negative float: 8 exponent bits + the top 4 mantissa bits
+constexpr int SEL_TIE = 4096;   // composites of the boundary bin kept for the exact selection
+constexpr int SEL_STATE = 4;    // per segment: [0] boundary-bin candidates written, [1] boundary bin, [2] how many of it are kept, [3] its population
+constexpr int SEL_WS = SEL_BINS + SEL_STATE;  // unsigned words of select workspace per segment (zeroed per call)
+
 struct DecodeBuffers {
   // scan
   unsigned* cand_key;   // [nseg][cand_cap]   float bits of cls*quality
   unsigned* cand_idx;   // [nseg][cand_cap]   loc*N + cls
   unsigned* cand_count; // [nseg]
+  // select (pre-NMS top-k)
+  unsigned* sel_ws;             // [nseg][SEL_WS]   score histogram + state, zeroed per call
+  unsigned long long* sel_tie;  // [nseg][SEL_TIE]  composites of the bin the k-th largest falls in
   // pool (per image)
   unsigned long long* pool_key;  // [B][pool_cap]  (sqrt-score bits << 32) | ~ordinal
   unsigned* pool_count;          // [B]

@@ -1255,6 +1255,8 @@ static int build_decode(sylph_ctx* c, Plan* P) {
   RET(c->dalloc((void**)&d.cand_key, (size_t)nseg * P->cand_cap * 4));
   RET(c->dalloc((void**)&d.cand_idx, (size_t)nseg * P->cand_cap * 4));
   RET(c->dalloc((void**)&d.cand_count, (size_t)nseg * 4));
+  RET(c->dalloc((void**)&d.sel_ws, (size_t)nseg * SEL_WS * 4));
+  RET(c->dalloc((void**)&d.sel_tie, (size_t)nseg * SEL_TIE * 8));
   RET(c->dalloc((void**)&d.pool_key, (size_t)B * pool * 8));
   RET(c->dalloc((void**)&d.pool_count, (size_t)B * 4));
   RET(c->dalloc((void**)&d.s_box, (size_t)B * pool * 16));

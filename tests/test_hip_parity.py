@@ -436,6 +436,31 @@ def test_many_class_decode_topk_matches_oracle(g1, N, thr, post):
         np.testing.assert_allclose(g["pred_boxes"].cpu().numpy(), w["pred_boxes"].numpy(), atol=1e-3)
 
 
+def test_decode_topk_with_piled_up_scores_matches_oracle(g1):
+    """Zero class codes: every class of a location has the SAME score, so the bin of the 1000-th largest holds far more
+    candidates than the select kernel's on-chip list -> the whole-buffer radix select path, and the k boundary falls inside
+    a run of exact ties (lower (location, class) index first, as the oracle's stable sort)."""
+    from oracle import decode as OD
+    from sylph_amd import synthetic as W
+    N, thr, post = 800, 0.05, 300  # 320 locations x 800 classes <= 262 144: the buffer holds every score
+    cfg = _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": thr, "MODEL.FCOS.POST_NMS_TOPK_TEST": post})
+    eng = _engine("f32", cfg)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.head(torch.zeros(N, 256, 1, 1), torch.zeros(N))
+    lo, rg, ct, io = [[t.cpu() for t in ts] for ts in eng.export_head()]
+    assert float(lo[0].abs().max()) == 0.0
+    want = OD.predict_proposals(lo, rg, ct, io, pre_nms_thresh=thr, post_nms_topk=post)
+    got = eng.decode(max_out=5000)  # the post-NMS keep takes every tie of the 300-th score: whole runs of classes
+    for i, (w, g) in enumerate(zip(want, got)):
+        w = OD.detector_postprocess(w, sizes[i], sizes[i][0], sizes[i][1])
+        assert g["scores"].numel() == w["scores"].numel() > post
+        np.testing.assert_array_equal(g["pred_classes"].cpu().numpy(), w["pred_classes"].numpy())
+        np.testing.assert_array_equal(g["locations"].cpu().numpy(), w["locations"].numpy())
+        np.testing.assert_allclose(g["scores"].cpu().numpy(), w["scores"].numpy(), atol=1e-5)
+
+
 def test_candidate_overflow_fails_loudly(g1):
     from sylph_amd import synthetic as W
     eng = _engine("f32", _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": 0.011}), cand_cap=64)
