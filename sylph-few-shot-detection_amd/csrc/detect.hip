@@ -46,11 +46,10 @@ constexpr int SCAN_STAGE = 2048;  // candidates a block collects in LDS before i
 // block collects its candidates in LDS (wave-aggregated LDS atomics: one per wave and iteration) and reserves global ranges with
 // one atomicAdd per flush -- a handful per block.  The order of the buffer is irrelevant: selection and sort work on the
 // composite (score, ~ordinal) keys.  The logits are the only HBM traffic that matters (4 bytes per score); a thread keeps
-// SCAN_UNROLL 16-byte loads in flight before it looks at any of them (W = 4 classes per load; W = 1 if the row pitch is odd).
+// SCAN_UNROLL 16-byte loads (4 classes of a location each) in flight before it looks at any of them.
 // The LDS list is sized for occupancy (16 KiB: 8 blocks per CU), not for the worst case: it is flushed once half full, and
 // the part of a wave's candidates that still does not fit (density above ~50 % of a round) is appended directly with one
 // global atomicAdd per wave.
-template <int W>
 __global__ __launch_bounds__(256) void decode_scan_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
                                                           const float* __restrict__ logits,
                                                           const float* __restrict__ pred, int pred_ld,
@@ -60,6 +59,7 @@ __global__ __launch_bounds__(256) void decode_scan_kernel(const DecodeCfg cfg, c
   const int r_begin = blockIdx.x * SCAN_ROWS;
   if (r_begin >= sg.nloc) return;
   const int r_end = min(sg.nloc, r_begin + SCAN_ROWS);
+  constexpr int W = 4;  // classes per load
   const int N = cfg.num_classes;
   const int G = (N + W - 1) / W;  // W-wide class groups per location
   const int total = (r_end - r_begin) * G;
@@ -117,12 +117,8 @@ __global__ __launch_bounds__(256) void decode_scan_kernel(const DecodeCfg cfg, c
         const float* prow = pred + ((size_t)sg.row0 + loc_u[u]) * pred_ld;
         qa[u] = cfg.quality_mode != 1 ? prow[4] : 0.f;
         qb[u] = cfg.quality_mode != 0 ? prow[5] : 0.f;
-        if constexpr (W == 4) {
-          const float4 v = *reinterpret_cast<const float4*>(src);
-          x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
-        } else {
-          x[u][0] = src[0];
-        }
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
       }
       r += step_r; g += step_g;
       if (g >= G) { g -= G; ++r; }
@@ -614,10 +610,9 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   (void)hipMemsetAsync(buf.pool_count, 0, sizeof(unsigned) * B, s);
   (void)hipMemsetAsync(buf.status, 0, sizeof(int), s);
   dim3 g1((max_nloc + SCAN_ROWS - 1) / SCAN_ROWS, nseg);
-  if ((cfg.logits_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0)
-    hipLaunchKernelGGL(decode_scan_kernel<4>, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
-  else
-    hipLaunchKernelGGL(decode_scan_kernel<1>, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
+  // the scan reads the logits 16 bytes at a time: rows are padded to a multiple of 32 classes by ensure_logits()
+  if ((cfg.logits_ld & 3) != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
   // blocks per level of the selection: one per 64 Ki candidate slots, so a few-way plan (84 000 slots) runs 2 and an
   // 866-way plan (1.8 M slots) 28
   int parts = (cfg.cand_cap + 65535) / 65536;
