@@ -409,6 +409,198 @@ __global__ __launch_bounds__(1024) void decode_finish_kernel(const DecodeCfg cfg
   pool.flush();
 }
 
+// ---- many-way episodes: last cls-tower GroupNorm + ReLU + class-conditional conv + scan in ONE pass ------------------------------
+// With hundreds of classes the logits are the largest tensor of the step (866 classes x 22 400 locations x 4 B = 77.6 MB per
+// image) and exist only to be thresholded: written by the conv, read back by the scan.  Here a wave keeps the normalised 32 x 256
+// activations of 32 locations in registers (the operand scheme of gn_logits_kernel: HBM -> registers -> MFMA, no LDS), walks the
+// class codes in 32-class tiles (16 MFMAs each, code fragments straight from L2, the next tile's loaded into the registers the
+// MFMAs have just consumed) and thresholds the 32 x 32 logits in the accumulator layout:
+//   phase A  per accumulator register: logit + bias above logit(thr) - 1e-2 ?  (one v_cmp = the wave's hit mask) -> hits are
+//            compacted into a wave-private LDS queue
+//   phase B  the queue is processed densely, 64 hits at a time: sigmoid, quality, the exact fp32 threshold tests of
+//            decode_scan_kernel, candidates into a wave-private LDS list that reserves a range of the (image, level) buffer with
+//            one global atomicAdd per ~1000 candidates.
+// No block-level synchronisation at all: same-wave LDS traffic is ordered.  The arithmetic is that of gn_apply + conv_igemm +
+// decode_scan (same fma / rounding of the GroupNorm, same MFMA and K order, same sigmoid): the candidate set is identical, which
+// tests/test_hip_parity.py::test_many_way_fused_scan_equals_unfused checks.  The logits buffer is not written; sylph_export_head
+// runs the unfused conv on demand.
+// packed code rows [>= 32 n_ct][256] -> MFMA fragment order: the 1 KiB a wave loads for (class tile ct, K step ks) is contiguous,
+// 16 bytes per lane (lane = 32 lh + l31 holds class 32 ct + l31, channels 16 ks + 8 lh .. + 7).  Read row-wise, the same load
+// touches 32 cache lines for 32 bytes each.
+__global__ void pack_code_fragments_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wf, int n_frag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte piece
+  if (i >= n_frag * 64) return;
+  const int lane = i & 63, f = i >> 6, ks = f & 15, ct = f >> 4, l31 = lane & 31, lh = lane >> 5;
+  *reinterpret_cast<bf16x8*>(wf + (size_t)i * 8) =
+      *reinterpret_cast<const bf16x8*>(w + ((size_t)ct * 32 + l31) * 256 + ks * 16 + lh * 8);
+}
+
+constexpr int LS_QCAP = 1024;  // hits of one class tile of a wave: 64 lanes x 16 scores
+constexpr int LS_CCAP = 1024;  // candidates a wave collects before it reserves a global range
+
+__global__ __launch_bounds__(256, 2) void logits_scan_kernel(const bf16_t* __restrict__ x, int ld, const float2* __restrict__ coef,
+                                                             const bf16_t* __restrict__ w /* fragment order */,
+                                                             const float* __restrict__ bias_scan /* -inf past N */,
+                                                             const SegDesc* __restrict__ segs, const int2* __restrict__ tiles,
+                                                             int n_tiles, const float* __restrict__ pred, int pred_ld,
+                                                             const DecodeCfg cfg, const DecodeBuffers buf) {
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  typedef short s16x2v __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  __shared__ __attribute__((aligned(16))) float cf[4][512];  // per wave: (a0, a1, b0, b1) per channel pair of its current segment
+  __shared__ unsigned q_x[4][LS_QCAP], q_id[4][LS_QCAP];      // hit queue: logit bits, (row of the group << 16) | class
+  __shared__ unsigned c_key[4][LS_CCAP], c_idx[4][LS_CCAP];   // candidates of the wave's current segment
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int N = cfg.num_classes, n_ct = (N + 31) >> 5;
+  const float thr = cfg.pre_nms_thresh;
+  const float x_min = (thr > 0.f && thr < 1.f) ? logf(thr / (1.f - thr)) - 1e-2f : (thr >= 1.f ? INFINITY : -INFINITY);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned cn = 0u;  // candidates in the wave's list (wave-uniform)
+  int cur_seg = -1;
+  auto flush = [&]() {  // wave-uniform
+    if (cn == 0u) return;
+    unsigned base = 0u;
+    if (lane == 0) base = atomicAdd(&buf.cand_count[cur_seg], cn);
+    base = __shfl(base, 0);
+    for (unsigned i = lane; i < cn; i += 64) {
+      const unsigned pos = base + i;
+      if (pos < (unsigned)cfg.cand_cap) {
+        buf.cand_key[(size_t)cur_seg * cfg.cand_cap + pos] = c_key[wave][i];
+        buf.cand_idx[(size_t)cur_seg * cfg.cand_cap + pos] = c_idx[wave][i];
+      }
+    }
+    cn = 0u;
+  };
+  bf16x8 Wf[16];  // A operand: lane (class l31 of the tile, k half lh); class tile 0 now, then always the NEXT tile's (see below)
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) Wf[ks] = *reinterpret_cast<const bf16x8*>(w + ((size_t)ks * 64 + lane) * 8);
+  float4 bnext[4];  // biases of the next class tile, in the accumulator layout
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bnext[q] = *reinterpret_cast<const float4*>(bias_scan + 8 * q + 4 * lh);
+  const int n_groups = n_tiles * 4, stride = gridDim.x * 4;
+  for (int g = blockIdx.x * 4 + wave; g < n_groups; g += stride) {
+    const int2 tl = tiles[g >> 2];
+    const int seg = tl.x, r0 = tl.y + (g & 3) * 32;
+    const SegDesc& sd = segs[seg];
+    const int nrows = sd.out_H * sd.out_W;
+    if (r0 >= nrows) continue;  // wave-uniform
+    if (seg != cur_seg) {
+      flush();
+      cur_seg = seg;
+      const float2* cp = coef + (size_t)seg * 256;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pr = lane + 64 * i;  // channel pair
+        const float2 c0 = cp[2 * pr], c1 = cp[2 * pr + 1];
+        *reinterpret_cast<float4*>(&cf[wave][4 * pr]) = make_float4(c0.x, c1.x, c0.y, c1.y);
+      }
+    }
+    const int row = r0 + l31;
+    const bool valid = row < nrows;
+    const size_t grow = (size_t)(sd.out_row0 + (valid ? row : nrows - 1));
+    const bf16_t* xp = x + grow * ld + lh * 8;
+    u32x4 yv[16];  // relu(GN(x)) of (row l31, channels 16 ks + 8 lh ..) as bf16: the B operand of every class tile
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) yv[ks] = *reinterpret_cast<const u32x4*>(xp + ks * 16);
+    // quality (centerness / IoU) of the lane's row, computed once per row group; rows past the segment never hit
+    const float q_row = quality_from(cfg.quality_mode != 1 ? pred[grow * pred_ld + 4] : 0.f,
+                                     cfg.quality_mode != 0 ? pred[grow * pred_ld + 5] : 0.f, cfg.quality_mode);
+    const float x_min_row = valid ? x_min : INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float* cq = &cf[wave][(ks * 16 + lh * 8) * 2];  // 4 channel pairs x (a0, a1, b0, b1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4 c4 = *reinterpret_cast<const float4*>(cq + 4 * e);
+        const f32x2v xf = {__uint_as_float(yv[ks][e] << 16), __uint_as_float(yv[ks][e] & 0xffff0000u)};
+        const f32x2v av = {c4.x, c4.y}, bv = {c4.z, c4.w};
+        const f32x2v r = __builtin_elementwise_fma(xf, av, bv);
+        bf16x2 pk;
+        pk[0] = (bf16_t)r[0];
+        pk[1] = (bf16_t)r[1];
+        const s16x2v z = {0, 0};
+        yv[ks][e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2v, pk), z));  // ReLU on the bf16 pair
+      }
+    }
+    for (int ct = 0; ct < n_ct; ++ct) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int ct_next = ct + 1 < n_ct ? ct + 1 : 0;  // the last tile reloads tile 0: the next row group starts with it
+      const bf16_t* wn = w + ((size_t)ct_next * 16 * 64 + lane) * 8;
+      float4 bcur[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[ks], __builtin_bit_cast(bf16x8, yv[ks]), acc, 0, 0, 0);
+        Wf[ks] = *reinterpret_cast<const bf16x8*>(wn + (size_t)ks * 64 * 8);
+      }
+      // the NEXT tile's biases ride behind its code fragments: nothing the epilogue below waits for is younger than them
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bnext[q] = *reinterpret_cast<const float4*>(bias_scan + ct_next * 32 + 8 * q + 4 * lh);
+      // phase A: D^T layout, register 4q + e of a lane is class 32 ct + 8q + 4 lh + e of row l31.  Classes past N carry a bias
+      // of -inf (bias_scan) and rows past the segment a bound of +inf: one add and one compare per score.
+      unsigned qn = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float bq[4] = {bcur[q].x, bcur[q].y, bcur[q].z, bcur[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = acc[4 * q + e] + bq[e];
+          const bool hit = xv > x_min_row;
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const unsigned pos = qn + (unsigned)__popcll(m & below);
+            q_x[wave][pos] = __float_as_uint(xv);
+            q_id[wave][pos] = ((unsigned)l31 << 16) | (unsigned)(ct * 32 + 8 * q + 4 * lh + e);
+          }
+          qn += (unsigned)__popcll(m);
+        }
+      }
+      // phase B
+      for (unsigned i0 = 0; i0 < qn; i0 += 64) {
+        const unsigned i = i0 + lane;
+        const bool act = i < qn;
+        const unsigned id = act ? q_id[wave][i] : 0u;
+        const float xv = act ? __uint_as_float(q_x[wave][i]) : 0.f;
+        const int rl = (int)(id >> 16), cls = (int)(id & 0xffffu);
+        const float qr = __shfl(q_row, rl);
+        const float p = sigmoid_f(xv);
+        bool pass = act && p > thr;
+        const float sc = p * qr;
+        if (cfg.thresh_with_ctr) pass = pass && sc > thr;
+        const unsigned long long m = __ballot(pass);
+        const unsigned cnt = (unsigned)__popcll(m);
+        if (cnt == 0u) continue;
+        if (cn + cnt > (unsigned)LS_CCAP) flush();
+        if (pass) {
+          const unsigned pos = cn + (unsigned)__popcll(m & below);
+          c_key[wave][pos] = __float_as_uint(sc);
+          c_idx[wave][pos] = (unsigned)((r0 + rl) * N + cls);
+        }
+        cn += cnt;
+      }
+    }
+  }
+  flush();
+}
+
+int launch_logits_scan(const void* x, int ld, const float2* coef, const void* w, void* wf_ws, const float* bias_scan,
+                       const SegDesc* segs, const int2* tiles, int n_tiles, const float* pred, int pred_ld, const DecodeCfg& cfg,
+                       const DecodeBuffers& buf, int nseg, hipStream_t s) {
+  if (cfg.num_classes <= 0 || cfg.num_classes >= 65536 || n_tiles <= 0) return (int)hipErrorInvalidValue;
+  (void)hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
+  const int n_frag = ((cfg.num_classes + 31) / 32) * 16;
+  hipLaunchKernelGGL(pack_code_fragments_kernel, dim3((n_frag * 64 + 255) / 256), dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wf_ws,
+                     n_frag);
+  const int grid = n_tiles < 2048 ? n_tiles : 2048;
+  hipLaunchKernelGGL(logits_scan_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ld, coef, (const bf16_t*)wf_ws, bias_scan,
+                     segs, tiles, n_tiles, pred, pred_ld, cfg, buf);
+  return (int)hipGetLastError();
+}
+
 // per image: bitonic sort (descending) of the pool keys in LDS, then decode the sorted candidates
 __global__ __launch_bounds__(1024) void decode_sort_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
                                                            const float* __restrict__ pred, int pred_ld,
@@ -605,14 +797,16 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const DecodeCfg cfg, con
 int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int max_nloc, int B, int nw_bound,
                   const float* logits, const float* pred, int pred_ld, const DecodeBuffers& buf,
                   const ImageOut* img_out_dev, float* out_boxes, float* out_scores, int* out_classes,
-                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, hipStream_t s) {
-  (void)hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
+                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, bool candidates_ready, hipStream_t s) {
   (void)hipMemsetAsync(buf.pool_count, 0, sizeof(unsigned) * B, s);
   (void)hipMemsetAsync(buf.status, 0, sizeof(int), s);
-  dim3 g1((max_nloc + SCAN_ROWS - 1) / SCAN_ROWS, nseg);
-  // the scan reads the logits 16 bytes at a time: rows are padded to a multiple of 32 classes by ensure_logits()
-  if ((cfg.logits_ld & 3) != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
+  if (!candidates_ready) {  // else logits_scan_kernel has filled the candidate buffers of this batch
+    (void)hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
+    dim3 g1((max_nloc + SCAN_ROWS - 1) / SCAN_ROWS, nseg);
+    // the scan reads the logits 16 bytes at a time: rows are padded to a multiple of 32 classes by ensure_logits()
+    if ((cfg.logits_ld & 3) != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
+  }
   // blocks per level of the selection: one per 64 Ki candidate slots, so a few-way plan (84 000 slots) runs 2 and an
   // 866-way plan (1.8 M slots) 28
   int parts = (cfg.cand_cap + 65535) / 65536;

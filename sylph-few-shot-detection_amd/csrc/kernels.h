@@ -104,10 +104,16 @@ int launch_export_nchw_f32(const float* src, float* dst, int C, int HW, int row0
 int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, hipStream_t s);
 
 // detect.hip
+// many-way class-conditional conv fused with the scan (detect.hip); x: raw cls-tower output, coef: its GroupNorm (a, b) per
+// (segment, channel), w: packed codes [>= 32 * ceil(N/32)][256] bf16, wf_ws: as many bytes of workspace (the codes in MFMA
+// fragment order), bias_scan: fp32 biases (zeros without a bias), -inf from class N up to the same row count
+int launch_logits_scan(const void* x, int ld, const float2* coef, const void* w, void* wf_ws, const float* bias_scan,
+                       const SegDesc* segs, const int2* tiles, int n_tiles, const float* pred, int pred_ld, const DecodeCfg& cfg,
+                       const DecodeBuffers& buf, int nseg, hipStream_t s);
 int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int max_nloc, int B, int nw_bound,
                   const float* logits, const float* pred, int pred_ld, const DecodeBuffers& buf,
                   const ImageOut* img_out_dev, float* out_boxes, float* out_scores, int* out_classes,
-                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, hipStream_t s);
+                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, bool candidates_ready, hipStream_t s);
 
 // codegen.hip
 struct LevelDesc { int row0; int H, W; float scale; };  // per (image, level): rows of the feature pyramid

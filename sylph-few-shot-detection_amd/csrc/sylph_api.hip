@@ -237,6 +237,7 @@ struct Plan {
   float* logits = nullptr;  // [rows][logits_ld]
   int logits_ld = 0, logits_cap_ld = 0, ncls = 0;
   void* code_w = nullptr;   // packed class codes [Npad][256]
+  void* code_wf = nullptr;  // the same in MFMA fragment order (logits_scan_kernel), same capacity
   int code_w_cap = 0;
   const SegDesc* head_segs = nullptr;
   const int2 *head_tiles = nullptr, *head_tiles32 = nullptr;
@@ -251,6 +252,12 @@ struct Plan {
   std::vector<OpFn> cls_logits_ops;  // the checkpoint's cls_logits conv on this plan's cls tower output (sylph_fcos_head_pretrained)
   const float* cls_logits_dst = nullptr;  // the logits buffer those ops were built for
   int cand_cap = 0, pool_cap = 0;
+  bool scan_fused = false;    // the candidate buffers were filled by logits_scan_kernel (many-way head): decode skips its scan
+  bool logits_stale = false;  // ... and the logits buffer was not written: sylph_export_head runs the unfused conv first
+  float* bias_pad = nullptr;  // fp32 class biases of the last sylph_fcos_head: [0, cap) zero-padded to the packed code rows; [cap, 2 cap) the
+                              // same with -inf from class N on (logits_scan_kernel: padded classes never pass the threshold)
+  int bias_pad_cap = 0;
+  bool has_bias = false;
   ImageOut* img_out_dev = nullptr;
   ImageOut* img_out_host = nullptr;
   hipEvent_t img_out_ev = nullptr;  // recorded after the H2D copy of img_out_host (guards its reuse without a stream sync)
@@ -1273,6 +1280,27 @@ static int build_decode(sylph_ctx* c, Plan* P) {
   return 0;
 }
 
+// more classes than when the decode buffers were built: grow the candidate buffers
+static int ensure_cand_cap(sylph_ctx* c, Plan* P) {
+  if (want_cand_cap(c, P) <= P->cand_cap) return 0;
+  const int nseg = P->B * c->cfg.nlevels;
+  P->cand_cap = want_cand_cap(c, P);
+  c->dfree(P->dbuf.cand_key); c->dfree(P->dbuf.cand_idx);
+  P->dbuf.cand_key = nullptr; P->dbuf.cand_idx = nullptr;
+  RET(c->dalloc((void**)&P->dbuf.cand_key, (size_t)nseg * P->cand_cap * 4));
+  RET(c->dalloc((void**)&P->dbuf.cand_idx, (size_t)nseg * P->cand_cap * 4));
+  return 0;
+}
+
+static DecodeCfg decode_cfg(const sylph_ctx* c, const Plan* P, int max_out) {
+  DecodeCfg d;
+  d.num_classes = P->ncls; d.logits_ld = P->logits_ld; d.pre_nms_thresh = c->cfg.pre_nms_thresh;
+  d.pre_nms_topk = c->cfg.pre_nms_topk; d.nms_thresh = c->cfg.nms_thresh; d.post_nms_topk = c->cfg.post_nms_topk;
+  d.thresh_with_ctr = c->cfg.thresh_with_ctr; d.quality_mode = c->cfg.quality_mode; d.cand_cap = P->cand_cap;
+  d.pool_cap = P->pool_cap; d.nlevels = c->cfg.nlevels; d.max_out = max_out;
+  return d;
+}
+
 static int build_support(sylph_ctx* c, Plan* P) {
   if (P->support_built) return 0;
   if (!c->has_codegen) return fail("code generator weights were not loaded");
@@ -1969,6 +1997,9 @@ static int ensure_logits(sylph_ctx* c, Plan* P, int N) {
     if (P->code_w) c->dfree(P->code_w);
     P->code_w = nullptr; P->code_w_cap = 0;
     RET(c->dalloc(&P->code_w, (size_t)Npad * 256 * c->esz()));
+    if (P->code_wf) c->dfree(P->code_wf);
+    P->code_wf = nullptr;
+    RET(c->dalloc(&P->code_wf, (size_t)Npad * 256 * c->esz()));
     P->code_w_cap = Npad;
   }
   P->logits_ld = Npad;
@@ -1984,6 +2015,7 @@ int sylph_import_head(sylph_ctx* c, int N, int level, const float* logits, const
   OwnerScope own(c, P);
   BUILD(build_head(c, P), P);
   if (!P->logits || N != P->ncls) RET(ensure_logits(c, P, N));
+  P->scan_fused = false; P->logits_stale = false;
   const int hw = P->hl[level] * P->wl[level];
   for (int b = 0; b < P->B; ++b) {
     const int row0 = b * P->Ltot + P->off[level];
@@ -2018,20 +2050,13 @@ int sylph_roi_align(sylph_ctx* c, const float* boxes, float* out) {
   return 0;
 }
 
-int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, int N) {
-  Plan* P = c->cur;
-  if (!P) return fail("no current batch");
-  if (N <= 0) return fail("class_code is empty");
-  if (!cls_conv) return fail("cls_conv is NULL");
-  OwnerScope own(c, P);
-  BUILD(build_head(c, P), P);
-  const size_t rows = (size_t)P->B * P->Ltot;
+// the class-conditional conv as its own launch(es): logits[rows][Npad] fp32 from the cls tower output, the packed codes and
+// P->bias_pad (sylph_fcos_head; sylph_export_head after a fused many-way head)
+static int run_cond_logits(sylph_ctx* c, Plan* P) {
+  const int N = P->ncls, Npad = P->logits_ld;
   const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
-  const int Npad = (N + bn - 1) / bn * bn;
-  RET(ensure_logits(c, P, N));
-  RET(run_ops(c, P->head_ops, "fcos_head"));
-  KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, c->stream), "pack_codes");
-  const float* bias = (c->cfg.cond_use_bias && cls_bias) ? cls_bias : nullptr;
+  const size_t rows = (size_t)P->B * P->Ltot;
+  const float* bias = P->has_bias ? P->bias_pad : nullptr;
   if (P->cls_coef) {
     if (bn == 32 && P->cls_ld == 256) {  // GroupNorm + ReLU + class-conditional conv in one HBM pass (head_fused.hip)
       const Plan* PP = P;
@@ -2059,6 +2084,51 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   return 0;
 }
 
+int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, int N) {
+  Plan* P = c->cur;
+  if (!P) return fail("no current batch");
+  if (N <= 0) return fail("class_code is empty");
+  if (!cls_conv) return fail("cls_conv is NULL");
+  OwnerScope own(c, P);
+  BUILD(build_head(c, P), P);
+  const size_t rows = (size_t)P->B * P->Ltot;
+  const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
+  const int Npad = (N + bn - 1) / bn * bn;
+  RET(ensure_logits(c, P, N));
+  RET(run_ops(c, P->head_ops, "fcos_head"));
+  KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, c->stream), "pack_codes");
+  // the biases, zero-padded to the packed code rows (device copy: the caller's buffer need not outlive this call)
+  if (Npad > P->bias_pad_cap) {
+    if (P->bias_pad) c->dfree(P->bias_pad);
+    P->bias_pad = nullptr; P->bias_pad_cap = 0;
+    RET(c->dalloc((void**)&P->bias_pad, (size_t)2 * Npad * sizeof(float)));
+    P->bias_pad_cap = Npad;
+  }
+  P->has_bias = c->cfg.cond_use_bias && cls_bias;
+  HIPCHK(hipMemsetAsync(P->bias_pad, 0, (size_t)Npad * sizeof(float), c->stream));
+  if (P->has_bias) HIPCHK(hipMemcpyAsync(P->bias_pad, cls_bias, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  P->scan_fused = false; P->logits_stale = false;
+  // Many-way episodes (bf16): conv + scan in one pass, the logits never reach HBM (detect.hip: logits_scan_kernel)
+  static const int fuse_scan_on = getenv("SYLPH_FUSE_SCAN") ? atoi(getenv("SYLPH_FUSE_SCAN")) : 1;
+  if (fuse_scan_on && c->dt == DT_BF16 && P->cls_coef && bn != 32 && P->cls_ld == 256 && N < 65536) {
+    BUILD(build_decode(c, P), P);
+    RET(ensure_cand_cap(c, P));
+    const DecodeCfg d = decode_cfg(c, P, 0);
+    float* bias_scan = P->bias_pad + P->bias_pad_cap;
+    HIPCHK(hipMemcpyAsync(bias_scan, P->bias_pad, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    if (Npad > N) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(bias_scan + N), (int)0xff800000u, (size_t)(Npad - N), c->stream));
+    const Plan* PP = P;
+    const int nseg = P->B * c->cfg.nlevels;
+    KCHK(timed_op(c, "logits_scan_kernel", 2.0 * (double)rows * N * 256.0, c->stream, [=](hipStream_t st) {
+           return launch_logits_scan(PP->cls_feat, 256, PP->cls_coef, PP->code_w, PP->code_wf, bias_scan, PP->head_segs, PP->head_tiles32,
+                                     PP->head_mtiles32, PP->pred, 8, d, PP->dbuf, nseg, st);
+         }), "logits_scan");
+    P->scan_fused = true; P->logits_stale = true;
+    return 0;
+  }
+  return run_cond_logits(c, P);
+}
+
 int sylph_fcos_head_pretrained(sylph_ctx* c, int* num_classes) {
   Plan* P = c->cur;
   if (!P) return fail("no current batch");
@@ -2074,6 +2144,7 @@ int sylph_fcos_head_pretrained(sylph_ctx* c, int* num_classes) {
     RET(add_conv(c, P->cls_logits_ops, c->cls_logits, P->cls_feat, P->cls_ld, P->logits, P->logits_ld, pyramid_segs(c, P), o));
     P->cls_logits_dst = P->logits;
   }
+  P->scan_fused = false; P->logits_stale = false;
   RET(run_ops(c, P->head_ops, "fcos_head"));
   if (P->cls_coef) KCHK(P->cls_apply(c->stream), "gn_apply (cls tower, last layer)");
   RET(run_ops(c, P->cls_logits_ops, "cls_logits"));
@@ -2085,6 +2156,11 @@ int sylph_export_head(sylph_ctx* c, int level, float* logits, float* reg, float*
   Plan* P = c->cur;
   if (!P || !P->head_built || !P->logits) return fail("sylph_fcos_head must be called first");
   if (level < 0 || level >= c->cfg.nlevels) return fail("bad level");
+  if (logits && P->logits_stale) {  // fused many-way head: the logits were never written
+    OwnerScope own(c, P);
+    RET(run_cond_logits(c, P));
+    P->logits_stale = false;
+  }
   const int hw = P->hl[level] * P->wl[level];
   for (int b = 0; b < P->B; ++b) {
     const int row0 = b * P->Ltot + P->off[level];
@@ -2105,14 +2181,7 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   if (max_out <= 0) return fail("max_out must be positive");
   OwnerScope own(c, P);
   BUILD(build_decode(c, P), P);
-  if (want_cand_cap(c, P) > P->cand_cap) {  // more classes than when the plan was built: grow the candidate buffers
-    const int nseg = P->B * c->cfg.nlevels;
-    P->cand_cap = want_cand_cap(c, P);
-    c->dfree(P->dbuf.cand_key); c->dfree(P->dbuf.cand_idx);
-    P->dbuf.cand_key = nullptr; P->dbuf.cand_idx = nullptr;
-    RET(c->dalloc((void**)&P->dbuf.cand_key, (size_t)nseg * P->cand_cap * 4));
-    RET(c->dalloc((void**)&P->dbuf.cand_idx, (size_t)nseg * P->cand_cap * 4));
-  }
+  RET(ensure_cand_cap(c, P));
   // img_out_host is rewritten below: wait only for the previous call's H2D copy of it (long finished in steady
   // state), not for the stream: the host must stay free to launch the next batch on another stream
   if (P->img_out_ev) HIPCHK(hipEventSynchronize(P->img_out_ev));
@@ -2127,16 +2196,12 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   }
   HIPCHK(hipMemcpyAsync(P->img_out_dev, P->img_out_host, sizeof(ImageOut) * P->B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(P->img_out_ev, c->stream));
-  DecodeCfg d;
-  d.num_classes = P->ncls; d.logits_ld = P->logits_ld; d.pre_nms_thresh = c->cfg.pre_nms_thresh;
-  d.pre_nms_topk = c->cfg.pre_nms_topk; d.nms_thresh = c->cfg.nms_thresh; d.post_nms_topk = c->cfg.post_nms_topk;
-  d.thresh_with_ctr = c->cfg.thresh_with_ctr; d.quality_mode = c->cfg.quality_mode; d.cand_cap = P->cand_cap;
-  d.pool_cap = P->pool_cap; d.nlevels = c->cfg.nlevels; d.max_out = max_out;
+  const DecodeCfg d = decode_cfg(c, P, max_out);
   const int L = c->cfg.nlevels;
   int nwb = (L * c->cfg.pre_nms_topk + 63) / 64;
   if (nwb > P->pool_cap / 64) nwb = P->pool_cap / 64;
   KCHK(launch_decode(d, P->dsegs, P->B * L, P->hl[0] * P->wl[0], P->B, nwb, P->logits, P->pred, 8, P->dbuf,
-                     P->img_out_dev, boxes, scores, classes, levels, locations, cand, counts, c->stream),
+                     P->img_out_dev, boxes, scores, classes, levels, locations, cand, counts, P->scan_fused, c->stream),
        "decode_nms");
   if (status) HIPCHK(hipMemcpyAsync(status, P->dbuf.status, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
   return 0;

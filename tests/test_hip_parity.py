@@ -436,6 +436,45 @@ def test_many_class_decode_topk_matches_oracle(g1, N, thr, post):
         np.testing.assert_allclose(g["pred_boxes"].cpu().numpy(), w["pred_boxes"].numpy(), atol=1e-3)
 
 
+@pytest.mark.parametrize("N,thr,scale,bq,twc", [(866, 0.03, 2.0, ["ctrness"], False), (337, 0.02, 2.0, ["ctrness", "iou"], True),
+                                                 (100, 0.05, 3.0, ["iou"], False), (33, 0.0, 1.0, ["ctrness"], False)])
+def test_many_way_fused_scan_equals_unfused(g1, N, thr, scale, bq, twc):
+    """bf16, more than 32 classes: the class-conditional conv and the score scan are ONE kernel (logits_scan_kernel), the logits
+    never reach HBM.  Its candidates must be those of the unfused path (GroupNorm apply -> conv_igemm -> decode_scan_kernel):
+    the detections of the fused step are compared bit for bit with a decode of the exported (unfused) logits, which are also
+    decoded by the oracle."""
+    from oracle import decode as OD
+    from sylph_amd import synthetic as W
+    cfg = _cfg(**{"MODEL.FCOS.INFERENCE_TH_TEST": thr, "MODEL.FCOS.POST_NMS_TOPK_TEST": 300, "MODEL.FCOS.BOX_QUALITY": bq,
+                  "MODEL.FCOS.THRESH_WITH_CTR": twc})
+    eng = _engine("bf16", cfg)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g1["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    codes = W.synthetic_codes(N, seed=77, scale=scale)
+    eng.profile_enable(True); eng.profile_read()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    fused = eng.decode(max_out=5000)
+    assert "logits_scan_kernel" in eng.profile_read()["kernels"], "the fused many-way head did not run"
+    eng.profile_enable(False)
+    lo, rg, ct, io = eng.export_head()  # runs the unfused conv on the same tower output
+    eng.import_head(lo, rg, ct, io)     # ... and its logits go through decode_scan_kernel
+    unfused = eng.decode(max_out=5000)
+    want = OD.predict_proposals([t.cpu() for t in lo], [t.cpu() for t in rg], [t.cpu() for t in ct], [t.cpu() for t in io],
+                                pre_nms_thresh=thr, post_nms_topk=300, thresh_with_ctr=twc, box_quality=bq)
+    n_l0 = int((lo[0][0].float().sigmoid() > thr).sum())
+    assert n_l0 > 100, f"too few candidates for a meaningful comparison ({n_l0})"
+    for i, (f, u, w) in enumerate(zip(fused, unfused, want)):
+        assert f["scores"].numel() == u["scores"].numel() > 0
+        for k in ("pred_classes", "fpn_levels", "locations", "scores", "pred_boxes"):
+            assert torch.equal(f[k], u[k]), f"image {i}: {k} differs between the fused and the unfused head"
+        w = OD.detector_postprocess(w, sizes[i], sizes[i][0], sizes[i][1])
+        assert f["scores"].numel() == w["scores"].numel()
+        np.testing.assert_array_equal(f["pred_classes"].cpu().numpy(), w["pred_classes"].numpy())
+        np.testing.assert_array_equal(f["locations"].cpu().numpy(), w["locations"].numpy())
+        np.testing.assert_allclose(f["scores"].cpu().numpy(), w["scores"].numpy(), atol=1e-5)
+
+
 def test_decode_topk_with_piled_up_scores_matches_oracle(g1):
     """Zero class codes: every class of a location has the SAME score, so the bin of the 1000-th largest holds far more
     candidates than the select kernel's on-chip list -> the whole-buffer radix select path, and the k boundary falls inside
