@@ -2110,7 +2110,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   P->scan_fused = false; P->logits_stale = false;
   // Many-way episodes (bf16): conv + scan in one pass, the logits never reach HBM (detect.hip: logits_scan_kernel)
   static const int fuse_scan_on = getenv("SYLPH_FUSE_SCAN") ? atoi(getenv("SYLPH_FUSE_SCAN")) : 1;
-  if (fuse_scan_on && c->dt == DT_BF16 && P->cls_coef && bn != 32 && P->cls_ld == 256 && N < 65536) {
+  if (fuse_scan_on && c->dt == DT_BF16 && P->cls_coef && (bn != 32 || fuse_scan_on == 2) && P->cls_ld == 256 && N < 65536) {
     BUILD(build_decode(c, P), P);
     RET(ensure_cand_cap(c, P));
     const DecodeCfg d = decode_cfg(c, P, 0);
