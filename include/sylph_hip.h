@@ -153,7 +153,9 @@ int sylph_codegen(sylph_ctx* ctx, const float* boxes_dev, float* code_out_dev);
  * the current batch holds n_classes x shots support images, class k = images [k * shots, (k + 1) * shots); boxes_dev
  * (n_classes * shots, 4); codes_out_dev (n_classes, 257).  The reference computes one class per call
  * (meta_one_stage_detector.py:229-254); per class the arithmetic here is the same (ROIAlign, tower, GroupNorm and the shot mean
- * are per image / per class), only the launches are shared.  CodeGenerator only (ROIEncoder: shots must equal the batch). */
+ * are per image / per class), only the launches are shared.  ROIEncoder (cg_type 1): shots = EVAL_SHOT; its encoder attends over
+ * the class axis of a (classes, shots, C) tensor and sees one class per call at inference (roi_encoder.py:184-186), so a class of the
+ * batch never meets another class's tokens here either: the codes are those of one call per class. */
 int sylph_codegen_classes(sylph_ctx* ctx, const float* boxes_dev, int shots, float* codes_out_dev);
 /* With cg_has_scale: the "cls_weight_norm" outputs of the last sylph_codegen[_classes] call (one fp32 per class), the factor
  * forward_normalize_code multiplies into the L2-normalised code (code_generator.py:838-840,987-993) -> pass them to

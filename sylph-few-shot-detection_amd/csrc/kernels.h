@@ -137,6 +137,6 @@ int launch_mscam(DType dt, const float* ctx, void* x, int S, const MsCamWeights&
 int launch_linear(int x_is_bf16, const void* x, int ldx, int S, const float* W, const float* b, int K, int O, float* y,
                   int ldy, int relu, float add, hipStream_t s);
 int launch_add_layernorm(float* x, const float* r, int S, const float* gamma, const float* beta, hipStream_t s);
-int launch_mean_tokens(const float* x, int S, float* out, hipStream_t s);
+int launch_mean_tokens(const float* x, int n_classes, int S, float* out, hipStream_t s);
 
 }  // namespace sylph

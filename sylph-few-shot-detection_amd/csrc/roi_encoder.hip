@@ -1,5 +1,5 @@
 // ROIEncoder code generator (LVIS variant) on gfx950: the pieces that are not convolutions.
-// All of it is tiny (S <= 16 shots of one class, 49 positions, 256 channels): fp32 VALU math with
+// All of it is tiny (the shots of a few classes, 49 positions, 256 channels): fp32 VALU math with
 // wavefront/LDS reductions, one workgroup per support shot / token / output feature.
 //
 // Reference arithmetic followed (paths relative to /root/reference):
@@ -191,12 +191,18 @@ int launch_mscam(DType dt, const float* ctx, void* x, int S, const MsCamWeights&
   return (int)hipGetLastError();
 }
 
-// ---- y[s][o] = act(x[s][:] . W[o][:] + b[o]) (+ add), S <= 16; one block per output feature -------
+// ---- y[s][o] = act(x[s][:] . W[o][:] + b[o]) (+ add); one block per output feature and 16 rows ----
 template <typename XT>
 __global__ __launch_bounds__(256) void linear_kernel(const XT* __restrict__ x, int ldx, int S,
                                                      const float* __restrict__ W, const float* __restrict__ b,
                                                      int K, float* __restrict__ y, int ldy, int relu, float add) {
   const int o = blockIdx.x, t = threadIdx.x;
+  {  // rows [16 blockIdx.y, +16): a row's arithmetic does not depend on how many rows the call has
+    const int s0 = blockIdx.y * 16;
+    x += (size_t)s0 * ldx;
+    y += (size_t)s0 * ldy;
+    S = min(16, S - s0);
+  }
   float acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -224,13 +230,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const XT* __restrict__ x, i
 
 int launch_linear(int x_is_bf16, const void* x, int ldx, int S, const float* W, const float* b, int K, int O, float* y,
                   int ldy, int relu, float add, hipStream_t s) {
-  if (S > 16) return -1;
+  if (S < 1) return -1;
+  const dim3 grid(O, (S + 15) / 16);
   if (x_is_bf16)
-    hipLaunchKernelGGL(linear_kernel<bf16_t>, dim3(O), dim3(256), 0, s, (const bf16_t*)x, ldx, S, W, b, K, y, ldy,
-                       relu, add);
+    hipLaunchKernelGGL(linear_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, S, W, b, K, y, ldy, relu, add);
   else
-    hipLaunchKernelGGL(linear_kernel<float>, dim3(O), dim3(256), 0, s, (const float*)x, ldx, S, W, b, K, y, ldy, relu,
-                       add);
+    hipLaunchKernelGGL(linear_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, S, W, b, K, y, ldy, relu, add);
   return (int)hipGetLastError();
 }
 
@@ -262,15 +267,16 @@ int launch_add_layernorm(float* x, const float* r, int S, const float* gamma, co
 }
 
 // ---- out[:] = mean_s x[s][:] (E = 256) --------------------------------------------------------------
+// one block per class: the S tokens of class c are rows [c S, (c + 1) S)
 __global__ void mean_tokens_kernel(const float* __restrict__ x, int S, float* __restrict__ out) {
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, c = blockIdx.x;
   float a = 0.f;
-  for (int s = 0; s < S; ++s) a += x[(size_t)s * 256 + t];
-  out[t] = a / (float)S;
+  for (int s = 0; s < S; ++s) a += x[((size_t)c * S + s) * 256 + t];
+  out[(size_t)c * 256 + t] = a / (float)S;
 }
 
-int launch_mean_tokens(const float* x, int S, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(mean_tokens_kernel, dim3(1), dim3(256), 0, s, x, S, out);
+int launch_mean_tokens(const float* x, int n_classes, int S, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(n_classes), dim3(256), 0, s, x, S, out);
   return (int)hipGetLastError();
 }
 

@@ -1363,8 +1363,10 @@ static int build_support_roienc(sylph_ctx* c, Plan* P) {
   if (!c->has_roienc) return fail("ROIEncoder weights were not loaded");
   RET(ensure_pyramid(c, P));
   const size_t e = c->esz();
+  // S support images = one or several classes of P->cur_shots images each (sylph_codegen_classes).  Everything up to the encoder
+  // is per image; the reference's encoder attends over the CLASS axis of a (classes, shots, C) tensor (roi_encoder.py:184-186)
+  // and always sees one class per call at inference, i.e. a length-1 sequence: here too a class never sees another one.
   const int S = P->B, L = c->cfg.nlevels, npos = 49;
-  if (S > 16) return fail("ROIEncoder: at most 16 shots per class are supported");
   std::vector<LevelDesc> lv;
   for (int b = 0; b < S; ++b)
     for (int l = 0; l < L; ++l)
@@ -1379,8 +1381,9 @@ static int build_support_roienc(sylph_ctx* c, Plan* P) {
   int maxhid = 1024;
   for (auto& l : c->re.layers) maxhid = l.l1.O > maxhid ? l.l1.O : maxhid;
   RET(c->dalloc((void**)&P->re_hid, (size_t)S * maxhid * 4));
-  RET(c->dalloc((void**)&P->re_cls, 256 * 4));
-  RET(c->dalloc((void**)&P->re_h, (size_t)2 * (c->cfg.head_fc_dim > 256 ? c->cfg.head_fc_dim : 256) * 4));
+  const int hdim = c->cfg.head_fc_dim > 256 ? c->cfg.head_fc_dim : 256;
+  RET(c->dalloc((void**)&P->re_cls, (size_t)S * 256 * 4));
+  RET(c->dalloc((void**)&P->re_h, (size_t)2 * S * hdim * 4));
   const std::vector<SegDesc> segs = image_segs(S, 7, 7, 7, 7);
   auto& ops = P->support_ops;
   const DType dt = c->dt;
@@ -1440,23 +1443,23 @@ static int build_support_roienc(sylph_ctx* c, Plan* P) {
   {
     float* cls = P->re_cls;
     float* x = tok;
-    ops.push_back([=](hipStream_t s) { return launch_mean_tokens(x, S, cls, s); });
+    ops.push_back([=](hipStream_t s) { return launch_mean_tokens(x, S / PP->cur_shots, PP->cur_shots, cls, s); });
     const float prior = -logf((1.f - 0.01f) / 0.01f);  // ROIEncoder hard-codes prior_prob = 0.01 (roi_encoder.py:139-140), whatever MODEL.FCOS.PRIOR_PROB says
     for (int head = 0; head < 2; ++head) {
       const std::vector<sylph_ctx::Lin>& fcs = head == 0 ? R.wh : R.bh;
       const float* in = cls;
-      float* h0 = P->re_h + (size_t)head * (c->cfg.head_fc_dim > 256 ? c->cfg.head_fc_dim : 256);
+      float* h0 = P->re_h + (size_t)head * S * hdim;
       for (size_t k = 0; k < fcs.size(); ++k) {
         const sylph_ctx::Lin f = fcs[k];
         const bool last = k + 1 == fcs.size();
         const float add = (last && head == 1) ? prior : 0.f;
         const int off = head == 0 ? 0 : 256;
         if (last) {
-          ops.push_back([=](hipStream_t s) {
-            return launch_linear(0, in, f.K, 1, f.W, f.b, f.K, f.O, PP->cur_code_out + off, f.O, 0, add, s);
+          ops.push_back([=](hipStream_t s) {  // class k -> row k of the (classes, 257) output
+            return launch_linear(0, in, f.K, S / PP->cur_shots, f.W, f.b, f.K, f.O, PP->cur_code_out + off, 257, 0, add, s);
           });
         } else {
-          ops.push_back([=](hipStream_t s) { return launch_linear(0, in, f.K, 1, f.W, f.b, f.K, f.O, h0, f.O, 1, 0.f, s); });
+          ops.push_back([=](hipStream_t s) { return launch_linear(0, in, f.K, S / PP->cur_shots, f.W, f.b, f.K, f.O, h0, f.O, 1, 0.f, s); });
           in = h0;
         }
       }
@@ -2212,7 +2215,6 @@ int sylph_codegen_classes(sylph_ctx* c, const float* boxes, int shots, float* co
   if (!P) return fail("no current batch");
   if (!boxes || !codes_out) return fail("NULL argument");
   if (shots < 1 || P->B % shots != 0) return fail("pooled_features.shape[0] " + std::to_string(P->B) + " Vs batch_size * num_shots: the batch is not a whole number of classes");
-  if (c->cfg.cg_type == 1 && shots != P->B) return fail("ROIEncoder: one class per call (its transformer runs over the class axis, roi_encoder.py:184-186)");
   OwnerScope own(c, P);
   if (c->cfg.cg_type == 1) BUILD(build_support_roienc(c, P), P);
   else BUILD(build_support(c, P), P);

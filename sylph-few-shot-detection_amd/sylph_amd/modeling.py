@@ -170,6 +170,14 @@ class ROIEncoder(HipComponent):
         code = self.engine.codegen(boxes)
         return {"cls_conv": code[:256].reshape(1, 256, 1, 1), "cls_bias": code[256:257].reshape(1)}
 
+    def forward_classes(self, boxes: torch.Tensor, shots: int):
+        """Several classes of EVAL_SHOT support boxes each in the current batch -> one code dict per class.  The launches are shared;
+        a class's tokens never meet another class's (the reference's encoder sees one class per call at inference: a length-1
+        sequence on its attention axis, roi_encoder.py:184-186), so the codes are those of __call__ per class."""
+        assert shots == self.eval_shot, f"{shots} support images per class, EVAL_SHOT is {self.eval_shot}"
+        codes = self.engine.codegen_classes(boxes, shots)
+        return [{"cls_conv": c[:256].reshape(1, 256, 1, 1), "cls_bias": c[256:257].reshape(1)} for c in codes]
+
 
 def build_code_generator(cfg, feature_channels, feature_levels, strides):
     """sylph/modeling/code_generator/build.py:30-39."""
@@ -280,12 +288,13 @@ class MetaOneStageDetector(nn.Module):
     def forward_class_codes(self, items: List[List[Dict[str, Any]]]) -> List[Dict[str, torch.Tensor]]:
         """Support-path throughput: the reference (and forward_class_code above) runs ONE class per call; here several classes
         share the backbone / code-generator launches of one batch (B = classes x shots).  `items`: loader items, each a list of
-        length 1 as in forward_class_code.  Falls back to one call per class when the generator cannot batch classes
-        (ROIEncoder), the shot counts differ or a record carries more than one box."""
+        length 1 as in forward_class_code.  Falls back to one call per class when the shot counts differ (or are not the
+        ROIEncoder's EVAL_SHOT) or a record carries more than one box."""
         assert not self.training, "Not for training"
         recs = [[rec for x in it for rec in x["support_set"]] for it in items]
         shots = len(recs[0]) if recs else 0
         batchable = (len(items) > 1 and hasattr(self.code_generator, "forward_classes") and shots > 0
+                     and getattr(self.code_generator, "eval_shot", None) in (None, shots)
                      and all(len(it) == 1 and len(r) == shots for it, r in zip(items, recs))
                      and all(len(rec["instances"].gt_boxes.tensor) == 1 for r in recs for rec in r))
         if not batchable:

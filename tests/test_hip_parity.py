@@ -379,6 +379,37 @@ def test_roi_encoder_matches_reference_golden(golden_dir, S):
     np.testing.assert_allclose(code[256], g[f"s{S}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_roi_encoder_classes_batched_equal_one_class_per_call(golden_dir, dtype):
+    """Two classes of 5 shots in ONE batch (sylph_codegen_classes with the ROIEncoder): class 0 is the reference golden's support set,
+    class 1 the same images in another order.  fp32: class 0 reproduces the golden code, and both codes are bit-identical to
+    one-class-per-call runs (a class never meets another class's tokens)."""
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g7_roi_encoder.npz"))
+    eng = _engine(dtype, _roienc_cfg())
+    eng.load_state_dict(W.roi_encoder_state_dict(seed=4))
+    feats = _feats(g, "s5_feat")
+    boxes = torch.from_numpy(g["s5_boxes"])
+    perm = torch.tensor([3, 0, 4, 1, 2])
+    feats2 = [torch.cat([f, f[perm]], dim=0) for f in feats]
+    boxes2 = torch.cat([boxes, boxes[perm]], dim=0)
+    eng.import_pyramid(feats2, (192, 256))
+    many = eng.codegen_classes(boxes2, 5).clone()
+    assert tuple(many.shape) == (2, 257)
+    singles = []
+    for fs, bx in ((feats, boxes), ([f[perm] for f in feats], boxes[perm])):
+        eng.import_pyramid(fs, (192, 256))
+        singles.append(eng.codegen(bx).clone())
+    if dtype == "f32":
+        np.testing.assert_allclose(many[0, :256].cpu().numpy(), g["s5_cls_conv"].reshape(-1), atol=1e-3, rtol=1e-3)
+        for k in range(2):
+            assert torch.equal(many[k], singles[k]), f"class {k}: batched code differs from the one-class call"
+    else:
+        for k in range(2):
+            assert F.cosine_similarity(many[k, :256], singles[k][:256], dim=0).item() > 0.9995
+    assert F.cosine_similarity(many[0, :256], many[1, :256], dim=0).item() > 0.999  # same support set, another order
+
+
 def test_roi_encoder_bf16_close(golden_dir):
     from sylph_amd import synthetic as W
     g = np.load(os.path.join(golden_dir, "g7_roi_encoder.npz"))
