@@ -242,15 +242,29 @@ __device__ __forceinline__ unsigned long long radix_select_desc(unsigned n, unsi
       if ((comp & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(comp >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned cum = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (cum + hist[d] >= remain) break;
-        cum += hist[d];
+    if (tid < 64) {
+      // digit d = the largest with count(digits > d) < remain <= count(digits >= d); lane l owns digits 4l .. 4l + 3
+      const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned above = 0u;  // count of the digits owned by higher lanes
+      for (int l = 0; l < 64; ++l) {
+        const unsigned v = __shfl(mine, l);
+        if (l > tid) above += v;
       }
-      *sh_prefix = prefix | ((unsigned long long)d << shift);
-      *sh_remain = remain - cum;
+      const bool here = above < remain && above + mine >= remain;
+      const unsigned long long found = __ballot(here);
+      if (here) {
+        unsigned cum = above;
+        int d = 4 * tid + 3;
+        if (cum + h3 < remain) { cum += h3; --d;
+          if (cum + h2 < remain) { cum += h2; --d;
+            if (cum + h1 < remain) { cum += h1; --d; } } }
+        *sh_prefix = prefix | ((unsigned long long)d << shift);
+        *sh_remain = remain - cum;
+      } else if (found == 0ull && tid == 0) {  // fewer than `remain` composites under this prefix (not reached by the callers)
+        *sh_prefix = prefix;
+        *sh_remain = remain - above - (mine - h0);
+      }
     }
     __syncthreads();
     prefix = *sh_prefix;

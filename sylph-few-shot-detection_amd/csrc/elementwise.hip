@@ -283,8 +283,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ x, const 
 // fixed order (fp64 Chan merges: 1024/ngroups interleaved chains per group, then the chains in index order) and
 // leaves (mean, rstd) per (segment, group).  Done once per layer: the fp64 chain (two divisions per tile) is far
 // too slow to repeat in every block of the streaming pass.
+// With `coef`: also the per (segment, channel) (a, b) of y = a * x + b (the apply pass of the NEXT conv: conv_hpipe.hip
+// transforms its input halo with these instead of a separate streaming pass over the tensor) -- one launch, not two.
 __global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const GnSeg* segs, int ngroups, const float* __restrict__ partial,
-                                                                   float eps, float2* __restrict__ stats) {
+                                                                   float eps, float2* __restrict__ stats,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float2* __restrict__ coef) {
   const GnSeg sg = segs[blockIdx.x];
   const int g = threadIdx.x % ngroups, sub = threadIdx.x / ngroups, nsub = 1024 / ngroups;
   __shared__ double sh[1024 * 3];
@@ -313,6 +317,15 @@ __global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const GnSeg*
     }
     const double var = N > 0.0 ? Q / N : 0.0;
     stats[(size_t)blockIdx.x * ngroups + g] = make_float2((float)M, (float)(1.0 / sqrt(var + (double)eps)));
+  }
+  if (coef) {
+    __syncthreads();  // the stats of this block's segment are visible to the block
+    const int c = threadIdx.x, C = ngroups * 8;
+    if (c < C) {
+      const float2 st = stats[(size_t)blockIdx.x * ngroups + (c >> 3)];
+      const float a = st.y * gamma[c];
+      coef[(size_t)blockIdx.x * C + c] = make_float2(a, beta[c] - st.x * a);
+    }
   }
 }
 
@@ -360,7 +373,8 @@ int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg
                              hipStream_t s) {
   if (ngroups != 32 && ngroups != 64) return -1;
   const int rpc = GN_ROWS_PER_CHUNK;
-  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(1024), 0, s, segs_dev, ngroups, partial, eps, stats_ws);
+  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(1024), 0, s, segs_dev, ngroups, partial, eps, stats_ws,
+                     (const float*)nullptr, (const float*)nullptr, (float2*)nullptr);
   dim3 grid((max_rows + rpc - 1) / rpc, nseg), block(256);
   if (dt == DT_BF16)
     hipLaunchKernelGGL(gn_apply_partials_kernel<bf16_t>, grid, block, 0, s, (bf16_t*)x, segs_dev, ld, ngroups, rpc, stats_ws, gamma,
@@ -371,22 +385,11 @@ int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg
   return (int)hipGetLastError();
 }
 
-// (mean, rstd) per (segment, group) + affine -> per (segment, channel) (a, b) with y = a * x + b (the apply pass of the NEXT
-// conv: conv_hpipe.hip transforms its input halo with these instead of a separate streaming pass over the tensor)
-__global__ void gn_coef_kernel(const float2* __restrict__ stats, int ngroups, const float* __restrict__ gamma,
-                               const float* __restrict__ beta, float2* __restrict__ coef) {
-  const int seg = blockIdx.x, c = threadIdx.x, C = ngroups * 8;
-  if (c >= C) return;
-  const float2 st = stats[(size_t)seg * ngroups + (c >> 3)];
-  const float a = st.y * gamma[c];
-  coef[(size_t)seg * C + c] = make_float2(a, beta[c] - st.x * a);
-}
-
 int launch_gn_finalize_coef(int ngroups, const GnSeg* segs_dev, int nseg, const float* partial, float2* stats_ws, const float* gamma,
                             const float* beta, float eps, float2* coef, hipStream_t s) {
   if (ngroups != 32 && ngroups != 64) return -1;
-  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(1024), 0, s, segs_dev, ngroups, partial, eps, stats_ws);
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(nseg), dim3(ngroups * 8), 0, s, stats_ws, ngroups, gamma, beta, coef);
+  hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(nseg), dim3(1024), 0, s, segs_dev, ngroups, partial, eps, stats_ws, gamma, beta,
+                     coef);
   return (int)hipGetLastError();
 }
 
