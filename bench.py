@@ -284,6 +284,33 @@ def main():
             eng.preprocess(sup1); eng.backbone(); eng.codegen(bx1)
         torch.cuda.synchronize()
         support_leg["S5_one_class_per_call"] = round(50 / (time.perf_counter() - ts), 1)
+    many_way = None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        # many-way episodes on the same backbone (BASELINE configs[2] / [3] head loads: 20 and 866 classes, 16 query images per step,
+        # synchronous steps): the class-conditional conv + score scan are one kernel there (logits_scan_kernel), top-k by histogram
+        many_way = {"unit": "images/s", "batch": 16, "code_scale": 1.5,
+                    "note": "R-50, synchronous steps; 866 classes at code scale 1.5 = ~5 % of the 14.5 M P3 scores above the threshold"}
+        q16 = queries[:16] if B >= 16 else dev_images(16, H, Wd, 7, device)
+        cfg_m = make_cfg()
+        cfg_m.MODEL.FCOS.POST_NMS_TOPK_TEST = 300  # the LVIS setting
+        eng_m = Engine(cfg_m, dtype=args.dtype, device=local_rank)
+        eng_m.load_state_dict(sd)
+        for nway in (20, 866):
+            cm = W.synthetic_codes(nway, seed=3, scale=1.5)
+            cwm, cbm = cm["cls_conv"].to(device), cm["cls_bias"].to(device)
+
+            def step_m():
+                eng_m.preprocess(q16); eng_m.backbone(); eng_m.head(cwm, cbm)
+                return eng_m.decode()
+            for _ in range(3):
+                step_m()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(8):
+                step_m()
+            torch.cuda.synchronize()
+            many_way[f"N{nway}"] = round(16 * 8 / (time.perf_counter() - ts), 1)
+        eng_m.close()
     if rank == 0 and world == 1 and not args.no_parity:
         parity = parity_bf16(sd, queries[:2], cls_conv, cls_bias, dets[:2])
     if world > 1:
@@ -360,6 +387,8 @@ def main():
                                      "the same step; never the headline value"}
         if support_leg is not None:
             out["support_path"] = support_leg
+        if many_way is not None:
+            out["many_way"] = many_way
         if parity is not None:
             out["parity_bf16"] = parity
         if world == 1 and not args.no_cpu_baseline:
