@@ -97,7 +97,6 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
   typedef bf16_t T;
   typedef int i32x8 __attribute__((ext_vector_type(8)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));  // ext_vector LDS accesses: hipcc adds no vmcnt(0) for them beside LDS-DMA
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     bn[i] = *src;
   }
   const float *s1 = bn, *b1 = bn + MID, *s2 = bn + 2 * MID, *b2 = bn + 3 * MID, *s3 = bn + 4 * MID, *b3 = bn + 4 * MID + C;
+  (void)b1; (void)b2; (void)s3; (void)b3;  // read through s1 / s2 offsets or kept in registers (below)
   // conv3's FrozenBN constants of this lane's 64 output channels stay in registers (P3 is VALU bound: 64 fewer LDS reads per tile)
   f32x4 s3r[2][4], b3r[2][4];
 #pragma unroll

@@ -3,9 +3,12 @@
 // Compiled with -ffp-contract=off: box and IoU arithmetic must round exactly like the fp32 reference.
 //
 // Pipeline (one launch each, batch-wide):
-//   scan    : sigmoid(logit) > thr -> candidate (score bits, loc*N+cls) appended per (image, level)
-//   select  : per (image, level): if count > pre_nms_topk, exact radix-select of the k largest
-//             (score, lower-index-first) composites; survivors go to the per-image pool with key
+//   scan    : sigmoid(logit) > thr -> candidate (score bits, loc*N+cls) appended per (image, level); with more than 32
+//             classes (bf16) the class-conditional conv and this scan are ONE kernel and the logits are never stored
+//             (logits_scan_kernel, below)
+//   select  : per (image, level): if count > pre_nms_topk, the k largest (score, lower-index-first) composites exactly:
+//             score histogram -> partition around the bin of the k-th largest -> radix select inside that bin
+//             (decode_hist / decode_partition / decode_finish); survivors go to the per-image pool with key
 //             (sqrt(score) bits << 32 | ~ordinal), ordinal = (level, location, class) rank
 //   sort    : per image bitonic sort (descending) in LDS, then box decode of the sorted candidates
 //   mask    : 64x64 blocks of the upper-triangular suppression matrix (same class && IoU > thr)
@@ -25,13 +28,8 @@ namespace sylph {
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-__device__ __forceinline__ float quality_of(const float* pred_row, int mode) {
-  if (mode == 0) return sigmoid_f(pred_row[4]);
-  if (mode == 1) return sigmoid_f(pred_row[5]);
-  return sqrtf(sigmoid_f(pred_row[5]) * sigmoid_f(pred_row[4]));
-}
-
-__device__ __forceinline__ float quality_from(float ctr_logit, float iou_logit, int mode) {  // = quality_of on loaded values
+// box quality of a location (fcos_outputs.py:938-959): centerness, IoU, or sqrt(IoU * centerness)
+__device__ __forceinline__ float quality_from(float ctr_logit, float iou_logit, int mode) {
   if (mode == 0) return sigmoid_f(ctr_logit);
   if (mode == 1) return sigmoid_f(iou_logit);
   return sqrtf(sigmoid_f(iou_logit) * sigmoid_f(ctr_logit));

@@ -197,7 +197,6 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
                                                            bf16_t* __restrict__ out, char* __restrict__ trash, int H, int W, int H2,
                                                            int W2, int H4, int W4, int tiles_y, int tiles_x, int ntiles) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
