@@ -192,25 +192,42 @@ __global__ __launch_bounds__(128) void tap_gather_kernel(const float* __restrict
   const SegDesc& sd = segs[tl.x];
   const int H = sd.out_H, W = sd.out_W, HWn = H * W, r0 = tl.y, tid = threadIdx.x, pitch = sw + 1;
   const int q4 = sw >> 2;  // float4s per record
+  // all of a thread's loads (<= 3 x 7 float4: sw <= 24 -> q4 <= 6, ceil(130 * 6 / 128) = 7) are issued before the first LDS store:
+  // the staging is a pure HBM stream, and one load per loop trip was latency-bound (2.1 TB/s)
+  constexpr int MAXIT = 7;
+  float4 v[3][MAXIT];
+#pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int first = r0 + (kh - 1) * W - 1;  // map-relative row of LDS record 0
     const float* pl = planes + ((size_t)kh * plane_rows + sd.out_row0) * sw;
-    for (int i = tid; i < 130 * q4; i += 128) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int i = tid + it * 128;
       const int rec = i / q4, c4 = i - rec * q4;
       const int rr = first + rec;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)rr < (unsigned)HWn) v = *reinterpret_cast<const float4*>(pl + (size_t)rr * sw + c4 * 4);
-      float* d = &sm[kh][rec * pitch + c4 * 4];
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      v[kh][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 130 * q4 && (unsigned)rr < (unsigned)HWn) v[kh][it] = *reinterpret_cast<const float4*>(pl + (size_t)rr * sw + c4 * 4);
+    }
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int i = tid + it * 128;
+      if (i < 130 * q4) {
+        const int rec = i / q4, c4 = i - rec * q4;
+        float* d = &sm[kh][rec * pitch + c4 * 4];
+        d[0] = v[kh][it].x; d[1] = v[kh][it].y; d[2] = v[kh][it].z; d[3] = v[kh][it].w;
+      }
     }
   }
   __syncthreads();
   const int r = r0 + tid;
   if (r >= HWn) return;
   const int y = r / W, xx = r - y * W;
-  float v[8];
+  float acc[8];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) v[n] = 0.f;
+  for (int n = 0; n < 8; ++n) acc[n] = 0.f;
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {  // fixed order: kh outer, kw inner
     if ((unsigned)(y + kh - 1) >= (unsigned)H) continue;
@@ -220,14 +237,14 @@ __global__ __launch_bounds__(128) void tap_gather_kernel(const float* __restrict
       const float* tp = &sm[kh][(tid + kw) * pitch + kw * cp];  // record of row r + (kh - 1) W + (kw - 1)
 #pragma unroll
       for (int n = 0; n < 8; ++n)
-        if (n < cp) v[n] += tp[n];
+        if (n < cp) acc[n] += tp[n];
     }
   }
   float* op = out + (size_t)(sd.out_row0 + r) * out_ld;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
     if (n >= cp) break;
-    float t = v[n] + bias[n];
+    float t = acc[n] + bias[n];
     if (n < mul_nch) t *= sd.mul;
     if (n < relu_nch) t = t > 0.f ? t : 0.f;
     op[n] = t;
