@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void gn_taps_kernel(const bf16_t* __restrict__
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   __shared__ __attribute__((aligned(16))) float cf[4][512];
+  constexpr int TR_PITCH = NT * 32 + 4;  // floats per row of the transpose tile (+4: the 16-byte row pieces of 8 lanes fall on different banks)
+  __shared__ __attribute__((aligned(16))) float tr[4][32 * TR_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   bf16x8 Wf[NT][16];
 #pragma unroll
@@ -164,19 +166,25 @@ __global__ __launch_bounds__(256) void gn_taps_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf[t][ks], __builtin_bit_cast(bf16x8, yv), acc[t], 0, 0, 0);
     }
-    if (valid) {
-      // column j = kh * sw + kw * cp + n (sw = slice width, a multiple of 4): the float4 group of a lane lies inside ONE kernel-row
-      // slice and goes to plane kh, record `grow`, so that pass 2 reads near-contiguous sw-float records per kernel row
+    // column j = kh * sw + kw * cp + n (sw = slice width, a multiple of 4): columns [kh sw, (kh + 1) sw) of a row are its record in
+    // plane kh, so that pass 2 reads near-contiguous sw-float records per kernel row.  The 32 rows of the group are contiguous in
+    // every plane (32 * sw floats): the accumulator tile is transposed through wave-private LDS and written as whole 16-byte
+    // pieces of that run, 1 KiB per store instruction (direct from the accumulator layout a store touched 32 records for 32 bytes each).
+    float* st = &tr[wave][0];
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = t * 32 + 8 * q + 4 * lh;
-          const int kh = j >= 2 * sw ? 2 : (j >= sw ? 1 : 0);
-          if (j < 3 * sw)
-            *reinterpret_cast<float4*>(out + ((size_t)kh * plane_rows + grow) * sw + (j - kh * sw)) =
-                make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
-        }
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(st + l31 * TR_PITCH + t * 32 + 8 * q + 4 * lh) =
+            make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]);
+    const int vrows = min(32, nrows - r0), q4 = sw >> 2;
+    const size_t grow0 = (size_t)sd.out_row0 + r0;
+    for (int kh = 0; kh < 3; ++kh) {
+      float* dst = out + ((size_t)kh * plane_rows + grow0) * sw;
+      for (int i = lane; i < vrows * q4; i += 64) {
+        const int row = i / q4, c4 = i - row * q4;
+        *reinterpret_cast<float4*>(dst + (size_t)i * 4) = *reinterpret_cast<const float4*>(st + row * TR_PITCH + kh * sw + c4 * 4);
+      }
     }
   }
 }
