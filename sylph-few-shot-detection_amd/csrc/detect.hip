@@ -740,7 +740,10 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const DecodeCfg cfg, con
   const size_t base = (size_t)img * cfg.pool_cap;
   const ImageOut io = img_out[img];
   const int K = cfg.post_nms_topk;
-  unsigned long long rem0 = 0ull, rem1 = 0ull;
+  // Boxes kept so far (pool positions).  The suppression word of chunk c is gathered when the walk REACHES c: one 8-byte load per
+  // kept box, all of them in flight at once, then a wave-wide OR.  (Pushing every kept box's whole mask row into running words cost
+  // one dependent 1-KiB row read per kept box -- 0.2 ms for 300 kept boxes -- most of it for chunks the early stop never visits.)
+  extern __shared__ unsigned short kept_pos[];  // [pool_cap]
   int kept_total = 0, nout = 0;
   float kth = -1.f;
   bool truncated = false;
@@ -749,7 +752,11 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const DecodeCfg cfg, con
     const unsigned bi = b0 + lane;
     const bool valid = bi < n;
     const unsigned long long d = (valid && cfg.nms_thresh > 0.f) ? buf.mask[(base + bi) * Wd + c] : 0ull;
-    unsigned long long cur = c < 64 ? shfl_u64(rem0, c) : shfl_u64(rem1, c - 64);
+    unsigned long long cur = 0ull;
+    if (cfg.nms_thresh > 0.f) {
+      for (int k = lane; k < kept_total; k += 64) cur |= buf.mask[(base + kept_pos[k]) * Wd + c];
+      for (int o = 32; o > 0; o >>= 1) cur |= shfl_u64(cur, lane ^ o);
+    }
     if (n - b0 < 64u) cur |= ~0ull << (n - b0);
     unsigned long long keptmask = 0ull;
     for (int b = 0; b < 64; ++b) {
@@ -759,19 +766,10 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const DecodeCfg cfg, con
         cur |= db;
       }
     }
-    if (cfg.nms_thresh > 0.f) {
-      unsigned long long km = keptmask;
-      while (km) {
-        const int b = __ffsll((long long)km) - 1;
-        km &= km - 1;
-        const unsigned long long* mr = buf.mask + (base + b0 + b) * Wd;
-        if (lane < nw && lane > c) rem0 |= mr[lane];
-        if (lane + 64 < nw && lane + 64 > c) rem1 |= mr[lane + 64];
-      }
-    }
     const int nk = __popcll(keptmask);
     const bool is_kept = (keptmask >> lane) & 1ull;
     const int rank = kept_total + __popcll(keptmask & ((1ull << lane) - 1ull));
+    if (is_kept) kept_pos[rank] = (unsigned short)bi;  // same-wave LDS traffic is ordered: visible to the next chunk's gather
     const float score = valid ? buf.s_score[base + bi] : 0.f;
     if (K > 0 && kth < 0.f && kept_total + nk >= K) {
       const unsigned long long sel = __ballot(is_kept && rank == K - 1);
@@ -840,7 +838,7 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   if (cfg.nms_thresh > 0.f) {
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nw_bound * (nw_bound + 1) / 2, 1, B), dim3(64), 0, s, cfg, buf);
   }
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, s, cfg, buf, img_out_dev, out_boxes, out_scores,
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), sizeof(unsigned short) * cfg.pool_cap, s, cfg, buf, img_out_dev, out_boxes, out_scores,
                      out_classes, out_levels, out_locations, out_cand, out_counts);
   return (int)hipGetLastError();
 }
