@@ -11,9 +11,9 @@
 //             (decode_hist / decode_partition / decode_finish); survivors go to the per-image pool with key
 //             (sqrt(score) bits << 32 | ~ordinal), ordinal = (level, location, class) rank
 //   sort    : per image bitonic sort (descending) in LDS, then box decode of the sorted candidates
-//   mask    : 64x64 blocks of the upper-triangular suppression matrix (same class && IoU > thr)
-//   reduce  : one wave per image walks 64-box chunks, keeps/suppresses, stops once post_nms_topk
-//             (+ score ties) are kept, applies rescale/clip/non-empty filter, writes the outputs.
+//   nms     : one block per image walks 64-box chunks of the sorted pool: suppression by the boxes kept so far (same class &&
+//             IoU > thr) computed for the visited chunks only, stops once post_nms_topk (+ score ties) are kept, applies
+//             rescale/clip/non-empty filter, writes the outputs.
 //
 // Reference arithmetic followed (paths relative to /root/reference):
 //   sylph/modeling/meta_fcos/fcos_outputs.py:904-1008 forward_for_single_feature_map
@@ -668,148 +668,167 @@ __global__ __launch_bounds__(1024) void decode_sort_kernel(const DecodeCfg cfg, 
   }
 }
 
-// suppression bits: block (cj, ci, img), 64 threads; thread t = box i = ci*64+t vs boxes of chunk cj
-__global__ __launch_bounds__(64) void nms_mask_kernel(const DecodeCfg cfg, const DecodeBuffers buf) {
-  // grid.x enumerates the upper triangle (ci <= cj) only: t = cj (cj + 1) / 2 + ci  (a square grid spent half of its
-  // 400 000 one-wave blocks on an immediate return: the launch was dispatch bound)
-  const int tri = blockIdx.x, img = blockIdx.z;
-  int cj = (int)((sqrtf(8.f * (float)tri + 1.f) - 1.f) * 0.5f);
-  while ((cj + 1) * (cj + 2) / 2 <= tri) ++cj;
-  while (cj * (cj + 1) / 2 > tri) --cj;
-  const int ci = tri - cj * (cj + 1) / 2;
-  unsigned n = buf.pool_count[img];
-  if (n > (unsigned)cfg.pool_cap) n = cfg.pool_cap;
-  if ((unsigned)ci * 64u >= n || (unsigned)cj * 64u >= n) return;
-  __shared__ __attribute__((aligned(16))) float jb[64][4];
-  __shared__ __attribute__((aligned(16))) int jc[64];
-  const int t = threadIdx.x;
-  const size_t base = (size_t)img * cfg.pool_cap;
-  const unsigned j = cj * 64 + t;
-  if (j < n) {
-    jb[t][0] = buf.s_box[(base + j) * 4 + 0]; jb[t][1] = buf.s_box[(base + j) * 4 + 1];
-    jb[t][2] = buf.s_box[(base + j) * 4 + 2]; jb[t][3] = buf.s_box[(base + j) * 4 + 3];
-    jc[t] = buf.s_cls[base + j];
-  } else {
-    jc[t] = -1;
-  }
-  __syncthreads();
-  const unsigned i = ci * 64 + t;
-  if (i >= n) return;
-  const float x1 = buf.s_box[(base + i) * 4 + 0], y1 = buf.s_box[(base + i) * 4 + 1];
-  const float x2 = buf.s_box[(base + i) * 4 + 2], y2 = buf.s_box[(base + i) * 4 + 3];
-  const int ic = buf.s_cls[base + i];
-  const float iarea = (x2 - x1) * (y2 - y1);
-  unsigned long long bits = 0ull;
-  const int jstart = (ci == cj) ? t + 1 : 0;
-  // the class test of four boxes per LDS read: with C classes only 1 / C of the pairs goes on to the IoU
-  for (int q = jstart >> 2; q < 16; ++q) {
-    const int4 c4 = *reinterpret_cast<const int4*>(&jc[4 * q]);
-    const int cq[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int jj = 4 * q + e;
-      if (cq[e] != ic || jj < jstart) continue;
-      const float4 b = *reinterpret_cast<const float4*>(jb[jj]);
-      const float xx1 = fmaxf(x1, b.x), yy1 = fmaxf(y1, b.y);
-      const float xx2 = fminf(x2, b.z), yy2 = fminf(y2, b.w);
-      const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-      const float inter = w * h;
-      const float jarea = (b.z - b.x) * (b.w - b.y);
-      const float ovr = inter / (iarea + jarea - inter);
-      if (ovr > cfg.nms_thresh) bits |= 1ull << jj;
-    }
-  }
-  buf.mask[(base + i) * (size_t)(cfg.pool_cap / 64) + cj] = bits;
-}
-
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
   const unsigned lo = __shfl((unsigned)(v & 0xffffffffull), src);
   const unsigned hi = __shfl((unsigned)(v >> 32), src);
   return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64) void nms_reduce_kernel(const DecodeCfg cfg, const DecodeBuffers buf,
-                                                        const ImageOut* __restrict__ img_out, float* out_boxes,
-                                                        float* out_scores, int* out_classes, int* out_levels,
-                                                        float* out_locations, int* out_cand, int* out_counts) {
-  const int img = blockIdx.x, lane = threadIdx.x;
+// IoU > thr for two boxes of the same class: torchvision's nms arithmetic (inter / (area_i + area_j - inter), no +1)
+__device__ __forceinline__ bool nms_overlap(float x1, float y1, float x2, float y2, float iarea, float4 b, float thr) {
+  const float xx1 = fmaxf(x1, b.x), yy1 = fmaxf(y1, b.y);
+  const float xx2 = fminf(x2, b.z), yy2 = fminf(y2, b.w);
+  const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  const float inter = w * h;
+  const float jarea = (b.z - b.x) * (b.w - b.y);
+  return inter / (iarea + jarea - inter) > thr;
+}
+
+// Class-aware greedy NMS + post-NMS keep + postprocess, one 1024-thread block per image, walking the score-sorted pool in chunks of
+// 64 boxes.  Per chunk:
+//   1  suppression by the boxes kept in EARLIER chunks: thread (box b = t & 63, slice t >> 6) tests box b against every 16th kept
+//      box (class first; the kept box is one broadcast 16-byte load per wave), the 16 per-wave ballots are OR-ed through LDS;
+//   2  the 64 x 64 suppression bits inside the chunk (four pairs per thread);
+//   3  wave 0 resolves the chunk serially (a box is kept iff no kept box before it suppresses it), applies the post-NMS keep
+//      (first post_nms_topk kept boxes + every later one whose score ties the K-th), rescales / clips / drops empty boxes and
+//      writes the outputs; the walk stops as soon as the next chunk's best score is below the K-th kept score.
+// Only the chunks the walk visits cost anything (typically 3-10 of up to 79), and there is no B x pool x pool / 64 suppression
+// matrix in HBM: rounds 1-3 built that matrix for ALL chunk pairs in a separate launch (0.19 ms at the headline shape, 0.5 GB).
+__global__ __launch_bounds__(1024) void nms_kernel(const DecodeCfg cfg, const DecodeBuffers buf, const ImageOut* __restrict__ img_out,
+                                                   float* out_boxes, float* out_scores, int* out_classes, int* out_levels,
+                                                   float* out_locations, int* out_cand, int* out_counts) {
+  extern __shared__ unsigned short kept_pos[];  // [pool_cap]: pool positions of the boxes kept so far
+  __shared__ unsigned long long s_part[16];
+  __shared__ unsigned s_d[64][2];                // suppression bits inside the chunk: word i = boxes of the chunk suppressed by box i
+  __shared__ float4 s_box4[64];
+  __shared__ int s_cls4[64];
+  __shared__ int s_kept_total, s_stop;
+  const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   unsigned n = buf.pool_count[img];
   if (n > (unsigned)cfg.pool_cap) n = cfg.pool_cap;
   const int nw = (int)((n + 63) / 64);
-  const size_t Wd = cfg.pool_cap / 64;
   const size_t base = (size_t)img * cfg.pool_cap;
   const ImageOut io = img_out[img];
   const int K = cfg.post_nms_topk;
-  // Boxes kept so far (pool positions).  The suppression word of chunk c is gathered when the walk REACHES c: one 8-byte load per
-  // kept box, all of them in flight at once, then a wave-wide OR.  (Pushing every kept box's whole mask row into running words cost
-  // one dependent 1-KiB row read per kept box -- 0.2 ms for 300 kept boxes -- most of it for chunks the early stop never visits.)
-  extern __shared__ unsigned short kept_pos[];  // [pool_cap]
-  int kept_total = 0, nout = 0;
+  const float thr = cfg.nms_thresh;
+  const bool nms_on = thr > 0.f;
+  int kept_total = 0, nout = 0;  // wave 0 keeps the running state; kept_total is mirrored in LDS for the other waves
   float kth = -1.f;
   bool truncated = false;
+  if (t == 0) { s_kept_total = 0; s_stop = 0; }
+  __syncthreads();
   for (int c = 0; c < nw; ++c) {
     const unsigned b0 = c * 64;
-    const unsigned bi = b0 + lane;
-    const bool valid = bi < n;
-    const unsigned long long d = (valid && cfg.nms_thresh > 0.f) ? buf.mask[(base + bi) * Wd + c] : 0ull;
-    unsigned long long cur = 0ull;
-    if (cfg.nms_thresh > 0.f) {
-      for (int k = lane; k < kept_total; k += 64) cur |= buf.mask[(base + kept_pos[k]) * Wd + c];
-      for (int o = 32; o > 0; o >>= 1) cur |= shfl_u64(cur, lane ^ o);
-    }
-    if (n - b0 < 64u) cur |= ~0ull << (n - b0);
-    unsigned long long keptmask = 0ull;
-    for (int b = 0; b < 64; ++b) {
-      const unsigned long long db = shfl_u64(d, b);
-      if (!((cur >> b) & 1ull)) {
-        keptmask |= 1ull << b;
-        cur |= db;
-      }
-    }
-    const int nk = __popcll(keptmask);
-    const bool is_kept = (keptmask >> lane) & 1ull;
-    const int rank = kept_total + __popcll(keptmask & ((1ull << lane) - 1ull));
-    if (is_kept) kept_pos[rank] = (unsigned short)bi;  // same-wave LDS traffic is ordered: visible to the next chunk's gather
-    const float score = valid ? buf.s_score[base + bi] : 0.f;
-    if (K > 0 && kth < 0.f && kept_total + nk >= K) {
-      const unsigned long long sel = __ballot(is_kept && rank == K - 1);
-      const int src = __ffsll((long long)sel) - 1;
-      kth = __shfl(score, src);
-    }
-    bool emit = is_kept && (K <= 0 || rank < K || score >= kth);
-    float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
-    if (emit) {
-      bx1 = buf.s_box[(base + bi) * 4 + 0] * io.sx; by1 = buf.s_box[(base + bi) * 4 + 1] * io.sy;
-      bx2 = buf.s_box[(base + bi) * 4 + 2] * io.sx; by2 = buf.s_box[(base + bi) * 4 + 3] * io.sy;
-      bx1 = fminf(fmaxf(bx1, 0.f), io.out_w); by1 = fminf(fmaxf(by1, 0.f), io.out_h);
-      bx2 = fminf(fmaxf(bx2, 0.f), io.out_w); by2 = fminf(fmaxf(by2, 0.f), io.out_h);
-      emit = (bx2 - bx1) > 0.f && (by2 - by1) > 0.f;
-    }
-    const unsigned long long em = __ballot(emit);
-    const int slot = nout + __popcll(em & ((1ull << lane) - 1ull));
-    if (emit) {
-      if (slot < cfg.max_out) {
-        const size_t o = (size_t)img * cfg.max_out + slot;
-        out_boxes[o * 4 + 0] = bx1; out_boxes[o * 4 + 1] = by1; out_boxes[o * 4 + 2] = bx2; out_boxes[o * 4 + 3] = by2;
-        out_scores[o] = score;
-        out_classes[o] = buf.s_cls[base + bi];
-        out_levels[o] = buf.s_level[base + bi];
-        out_locations[o * 2 + 0] = buf.s_loc[(base + bi) * 2 + 0];
-        out_locations[o * 2 + 1] = buf.s_loc[(base + bi) * 2 + 1];
-        out_cand[o] = (int)buf.s_ord[base + bi];
+    // the chunk's boxes -> LDS (wave 0), suppression words cleared
+    if (wave == 0) {
+      const unsigned bi = b0 + lane;
+      if (bi < n) {
+        s_box4[lane] = *reinterpret_cast<const float4*>(buf.s_box + (base + bi) * 4);
+        s_cls4[lane] = buf.s_cls[base + bi];
       } else {
-        truncated = true;
+        s_box4[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_cls4[lane] = -1 - lane;  // matches nothing
       }
+      s_d[lane][0] = 0u; s_d[lane][1] = 0u;
     }
-    nout += __popcll(em);
-    kept_total += nk;
-    if (K > 0 && kept_total >= K && c + 1 < nw) {
-      const float next_score = buf.s_score[base + b0 + 64];
-      if (next_score < kth) break;
+    __syncthreads();
+    const int ktot = s_kept_total;
+    const float4 mb = s_box4[lane];
+    const int mc = s_cls4[lane];
+    bool sup = false;
+    if (nms_on) {
+      // 1: against the kept boxes of earlier chunks (kept box = the earlier, higher-scored one: "i" of the pair)
+      for (int k = wave; k < ktot; k += 16) {
+        const size_t kp = base + kept_pos[k];
+        if (buf.s_cls[kp] != mc) continue;
+        const float4 kb = *reinterpret_cast<const float4*>(buf.s_box + kp * 4);
+        const float karea = (kb.z - kb.x) * (kb.w - kb.y);
+        sup = sup || nms_overlap(kb.x, kb.y, kb.z, kb.w, karea, mb, thr);
+      }
+      // 2: inside the chunk: thread -> box i = t >> 4 against boxes j = 4 (t & 15) .. + 3, j > i
+      const int i = t >> 4, jq = t & 15;
+      const float4 ib = s_box4[i];
+      const int ic = s_cls4[i];
+      const float iarea = (ib.z - ib.x) * (ib.w - ib.y);
+      unsigned bits = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = 4 * jq + e;
+        if (j > i && s_cls4[j] == ic && nms_overlap(ib.x, ib.y, ib.z, ib.w, iarea, s_box4[j], thr)) bits |= 1u << (j & 31);
+      }
+      if (bits) atomicOr(&s_d[i][jq >> 3], bits);
     }
+    const unsigned long long part = __ballot(sup);
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    if (wave == 0) {
+      // 3: serial resolve + emit (the arithmetic and order of the former nms_reduce_kernel)
+      const unsigned bi = b0 + lane;
+      const bool valid = bi < n;
+      unsigned long long cur = 0ull;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) cur |= s_part[w];
+      if (n - b0 < 64u) cur |= ~0ull << (n - b0);
+      const unsigned long long d = ((unsigned long long)s_d[lane][1] << 32) | (unsigned long long)s_d[lane][0];
+      unsigned long long keptmask = 0ull;
+      for (int b = 0; b < 64; ++b) {
+        const unsigned long long db = shfl_u64(d, b);
+        if (!((cur >> b) & 1ull)) {
+          keptmask |= 1ull << b;
+          cur |= db;
+        }
+      }
+      const int nk = __popcll(keptmask);
+      const bool is_kept = (keptmask >> lane) & 1ull;
+      const int rank = kept_total + __popcll(keptmask & ((1ull << lane) - 1ull));
+      if (is_kept) kept_pos[rank] = (unsigned short)bi;
+      const float score = valid ? buf.s_score[base + bi] : 0.f;
+      if (K > 0 && kth < 0.f && kept_total + nk >= K) {
+        const unsigned long long sel = __ballot(is_kept && rank == K - 1);
+        const int src = __ffsll((long long)sel) - 1;
+        kth = __shfl(score, src);
+      }
+      bool emit = is_kept && (K <= 0 || rank < K || score >= kth);
+      float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
+      if (emit) {
+        bx1 = mb.x * io.sx; by1 = mb.y * io.sy;
+        bx2 = mb.z * io.sx; by2 = mb.w * io.sy;
+        bx1 = fminf(fmaxf(bx1, 0.f), io.out_w); by1 = fminf(fmaxf(by1, 0.f), io.out_h);
+        bx2 = fminf(fmaxf(bx2, 0.f), io.out_w); by2 = fminf(fmaxf(by2, 0.f), io.out_h);
+        emit = (bx2 - bx1) > 0.f && (by2 - by1) > 0.f;
+      }
+      const unsigned long long em = __ballot(emit);
+      const int slot = nout + __popcll(em & ((1ull << lane) - 1ull));
+      if (emit) {
+        if (slot < cfg.max_out) {
+          const size_t o = (size_t)img * cfg.max_out + slot;
+          out_boxes[o * 4 + 0] = bx1; out_boxes[o * 4 + 1] = by1; out_boxes[o * 4 + 2] = bx2; out_boxes[o * 4 + 3] = by2;
+          out_scores[o] = score;
+          out_classes[o] = mc;
+          out_levels[o] = buf.s_level[base + bi];
+          out_locations[o * 2 + 0] = buf.s_loc[(base + bi) * 2 + 0];
+          out_locations[o * 2 + 1] = buf.s_loc[(base + bi) * 2 + 1];
+          out_cand[o] = (int)buf.s_ord[base + bi];
+        } else {
+          truncated = true;
+        }
+      }
+      nout += __popcll(em);
+      kept_total += nk;
+      bool stop = false;
+      if (K > 0 && kept_total >= K && c + 1 < nw) {
+        const float next_score = buf.s_score[base + b0 + 64];
+        stop = next_score < kth;
+      }
+      if (lane == 0) { s_kept_total = kept_total; s_stop = stop ? 1 : 0; }
+    }
+    __syncthreads();
+    if (s_stop) break;
   }
-  if (__any(truncated) && lane == 0) atomicOr(buf.status, 2);
-  if (lane == 0) out_counts[img] = nout < cfg.max_out ? nout : cfg.max_out;
+  if (wave == 0) {
+    if (__any(truncated) && lane == 0) atomicOr(buf.status, 2);
+    if (lane == 0) out_counts[img] = nout < cfg.max_out ? nout : cfg.max_out;
+  }
 }
 
 int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int max_nloc, int B, int nw_bound,
@@ -835,10 +854,8 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   hipLaunchKernelGGL(decode_finish_kernel, dim3(nseg), dim3(1024), 0, s, cfg, segs_dev, buf);
   hipLaunchKernelGGL(decode_sort_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * cfg.pool_cap, s, cfg,
                      segs_dev, pred, pred_ld, buf);
-  if (cfg.nms_thresh > 0.f) {
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw_bound * (nw_bound + 1) / 2, 1, B), dim3(64), 0, s, cfg, buf);
-  }
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), sizeof(unsigned short) * cfg.pool_cap, s, cfg, buf, img_out_dev, out_boxes, out_scores,
+  (void)nw_bound;
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), sizeof(unsigned short) * cfg.pool_cap, s, cfg, buf, img_out_dev, out_boxes, out_scores,
                      out_classes, out_levels, out_locations, out_cand, out_counts);
   return (int)hipGetLastError();
 }

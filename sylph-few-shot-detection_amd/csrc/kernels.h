@@ -64,7 +64,6 @@ struct DecodeBuffers {
   int* s_level;      // [B][pool_cap]
   float* s_loc;      // [B][pool_cap][2]
   unsigned* s_ord;   // [B][pool_cap]
-  unsigned long long* mask;  // [B][pool_cap][pool_cap/64]
   int* status;       // [1] bit0: candidate overflow, bit1: output truncated
 };
 

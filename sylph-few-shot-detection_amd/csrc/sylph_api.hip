@@ -1272,7 +1272,6 @@ static int build_decode(sylph_ctx* c, Plan* P) {
   RET(c->dalloc((void**)&d.s_level, (size_t)B * pool * 4));
   RET(c->dalloc((void**)&d.s_loc, (size_t)B * pool * 8));
   RET(c->dalloc((void**)&d.s_ord, (size_t)B * pool * 4));
-  RET(c->dalloc((void**)&d.mask, (size_t)B * pool * (pool / 64) * 8));
   RET(c->dalloc((void**)&d.status, 4));
   RET(c->dalloc((void**)&P->img_out_dev, sizeof(ImageOut) * B));
   HIPCHK(hipHostMalloc((void**)&P->img_out_host, sizeof(ImageOut) * B));
