@@ -35,7 +35,7 @@ __device__ __forceinline__ float quality_from(float ctr_logit, float iou_logit, 
   return sqrtf(sigmoid_f(iou_logit) * sigmoid_f(ctr_logit));
 }
 
-constexpr int SCAN_ROWS = 64;
+constexpr int SCAN_ROWS = 64;     // minimum locations per block
 constexpr int SCAN_UNROLL = 4;    // loads in flight per thread (16 B each on the vector path)
 constexpr int SCAN_STAGE = 2048;  // candidates a block collects in LDS before it reserves a range of the (image, level) buffer
 
@@ -51,12 +51,12 @@ constexpr int SCAN_STAGE = 2048;  // candidates a block collects in LDS before i
 __global__ __launch_bounds__(256) void decode_scan_kernel(const DecodeCfg cfg, const DecodeSeg* __restrict__ segs,
                                                           const float* __restrict__ logits,
                                                           const float* __restrict__ pred, int pred_ld,
-                                                          const DecodeBuffers buf) {
+                                                          const DecodeBuffers buf, int rows_per_block) {
   const int seg = blockIdx.y;
   const DecodeSeg sg = segs[seg];
-  const int r_begin = blockIdx.x * SCAN_ROWS;
+  const int r_begin = blockIdx.x * rows_per_block;
   if (r_begin >= sg.nloc) return;
-  const int r_end = min(sg.nloc, r_begin + SCAN_ROWS);
+  const int r_end = min(sg.nloc, r_begin + rows_per_block);
   constexpr int W = 4;  // classes per load
   const int N = cfg.num_classes;
   const int G = (N + W - 1) / W;  // W-wide class groups per location
@@ -839,10 +839,15 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   (void)hipMemsetAsync(buf.status, 0, sizeof(int), s);
   if (!candidates_ready) {  // else logits_scan_kernel has filled the candidate buffers of this batch
     (void)hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
-    dim3 g1((max_nloc + SCAN_ROWS - 1) / SCAN_ROWS, nseg);
+    // locations per block: at least SCAN_ROWS, and enough for ~16 K scores (a 5-class episode has 8 score slots per location: 64
+    // locations would be half a round of the block, and 84 000 such blocks a dispatch-bound launch)
+    const int groups = (cfg.num_classes + 3) / 4;
+    int rows_per_block = (4096 + groups - 1) / groups;
+    if (rows_per_block < SCAN_ROWS) rows_per_block = SCAN_ROWS;
+    dim3 g1((max_nloc + rows_per_block - 1) / rows_per_block, nseg);
     // the scan reads the logits 16 bytes at a time: rows are padded to a multiple of 32 classes by ensure_logits()
     if ((cfg.logits_ld & 3) != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf);
+    hipLaunchKernelGGL(decode_scan_kernel, g1, dim3(256), 0, s, cfg, segs_dev, logits, pred, pred_ld, buf, rows_per_block);
   }
   // blocks per level of the selection: one per 64 Ki candidate slots, so a few-way plan (84 000 slots) runs 2 and an
   // 866-way plan (1.8 M slots) 28
