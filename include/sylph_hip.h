@@ -89,7 +89,10 @@ int sylph_finalize_weights(sylph_ctx* ctx);
 /* MetaProposalNetwork.convert_batched_inputs_to_image_list
  * (sylph/modeling/meta_arch/meta_one_stage_detector.py:174-178): B device images, each (3,h,w) fp32
  * BGR 0-255 -> normalised, zero padded to a common size divisible by size_divisibility.
- * Host arrays: images_dev[B], heights[B], widths[B].  Returns the padded size. */
+ * Host arrays: images_dev[B], heights[B], widths[B].  Returns the padded size.
+ * bf16 mode: the normalisation is applied by the stem kernel of the next sylph_backbone_fpn call on the way into its LDS patch (same
+ * arithmetic, bit-identical; no normalised copy of the batch is written) -- the images must stay valid and unchanged until that call
+ * has been enqueued, on the same stream.  SYLPH_FUSE_PREPROCESS=0: a separate pass here. */
 int sylph_preprocess(sylph_ctx* ctx, int B, const float* const* images_dev, const int* heights, const int* widths,
                      int* padded_h, int* padded_w);
 

@@ -87,7 +87,10 @@ int launch_gn_pred_taps(const void* x, int ld, const float2* coef, const void* w
                         float* planes_ws, size_t plane_rows, float* out, int out_ld, const SegDesc* segs, const int2* tiles, int n_tiles,
                         hipStream_t s);  // head_fused.hip: last bbox-tower GroupNorm + 3x3 prediction convs (bf16)
 int launch_stem_pool(const void* x, const void* wp, const float* scale, const float* shift, void* out, void* trash, int B, int H, int W,
-                     int H2, int W2, int H4, int W4, hipStream_t s);  // stem + max-pool fused (bf16); trash >= 512 x 256 x 16 B
+                     int H2, int W2, int H4, int W4, hipStream_t s);
+constexpr int STEM_RAW_MAX_BATCH = 512;  // the image table of launch_stem_pool_raw lives in LDS
+int launch_stem_pool_raw(const ImageDesc* imgs_dev, const float* mean, const float* stdv, const void* wp, const float* scale,
+                         const float* shift, void* out, void* trash, int B, int H, int W, int H2, int W2, int H4, int W4, hipStream_t s);  // stem + max-pool fused (bf16); trash >= 512 x 256 x 16 B
 int launch_gn_apply_partials(DType dt, void* x, int ld, int ngroups, const GnSeg* segs_dev, int nseg, int max_rows,
                              const float* partial, float2* stats_ws, const float* gamma, const float* beta, float eps, int relu,
                              hipStream_t s);

@@ -15,6 +15,7 @@
 //     epilogue goes through an fp32 LDS tile like conv_igemm.hip (scale/shift, ReLU, 16-byte stores);
 //   * persistent blocks (grid-stride over tiles); the patches of the next two tiles are in flight in registers.
 #include "common.h"
+#include "kernels.h"
 
 namespace sylph {
 
@@ -192,17 +193,28 @@ constexpr int FNLOAD = (FPROWS * FPCOLS + 255) / 256;  // 6
 constexpr int FLDS = FPATCH_BYTES + ((FTILE_BYTES + 127) / 128) * 128 + 128 * 4;
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+// RAW = true: the network-input normalisation of `preprocess_kernel` (elementwise.hip) is applied HERE, on the way from the
+// caller's fp32 (3, h, w) planes into the LDS patch -- (p - mean) * (1 / std) rounded to bf16, zero outside the image's own
+// h x w, the same arithmetic, so the result is bit-identical -- and the [B][H][W][4] bf16 copy of the batch (0.55 GB written and
+// read back at B = 64) is never made.  Three 4-byte loads per patch pixel instead of one 8-byte load.
+struct StemRawArgs { const ImageDesc* imgs; int B; float m0, m1, m2, is0, is1, is2; };
+
+template <bool RAW>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restrict__ x, const StemRawArgs raw, const bf16_t* __restrict__ wp,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            bf16_t* __restrict__ out, char* __restrict__ trash, int H, int W, int H2,
                                                            int W2, int H4, int W4, int tiles_y, int tiles_x, int ntiles) {
+  constexpr int NV = RAW ? 3 * FNLOAD : FNLOAD;  // VMEM loads per thread and tile
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
   char* st = smem + FPATCH_BYTES;
   float* ss = reinterpret_cast<float*>(smem + FPATCH_BYTES + ((FTILE_BYTES + 127) / 128) * 128);  // scale[64], shift[64]
+  ImageDesc* descs = reinterpret_cast<ImageDesc*>(smem + FLDS);  // RAW: the batch's image table (a global read per tile would join the counted vmcnt queue)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  if (RAW)
+    for (int i = tid; i < raw.B; i += 256) descs[i] = raw.imgs[i];
 
   bf16x8 wb[14][2];
 #pragma unroll
@@ -244,26 +256,59 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
     const int tx = tile % tiles_x, t2 = tile / tiles_x, ty = t2 % tiles_y;
     b = t2 / tiles_y; oy0 = ty * FPR; ox0 = tx * FPC;
   };
-  auto fetch = [&](int tile_in, uint2 (&v)[FNLOAD], uint32_t& okmask) {
+  // v: RAW ? three fp32 planes per pixel (v[3 r + c]) : the packed bf16 pixel in (v[2 r], v[2 r + 1])
+  auto fetch = [&](int tile_in, unsigned (&v)[3 * FNLOAD], uint32_t& okmask) {
     int b, oy0, ox0;
     tile_origin(tile_in < ntiles ? tile_in : ntiles - 1, b, oy0, ox0);
     const int iy0 = 4 * oy0 - 5, ix0 = 4 * ox0 - 5;  // stem row 2 oy0 - 1 reads input rows 2 (2 oy0 - 1) - 3 ..
     okmask = 0;
-    const bf16_t* xb = x + (size_t)b * H * W * 4;
+    if (RAW) {
+      const ImageDesc d = descs[b];
+      const size_t plane = (size_t)d.h * d.w;
 #pragma unroll
-    for (int r = 0; r < FNLOAD; ++r) {
-      const int iy = iy0 + f_pr[r], ix = ix0 + f_pc[r];
-      const bool ok = ((f_in >> r) & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-      const bf16_t* src = xb + (cy * W + cx) * 4;
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v[r]) : "v"(src) : "memory");
-      okmask |= (ok ? 1u : 0u) << r;
+      for (int r = 0; r < FNLOAD; ++r) {
+        const int iy = iy0 + f_pr[r], ix = ix0 + f_pc[r];
+        const bool ok = ((f_in >> r) & 1u) && (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+        const int cy = min(max(iy, 0), d.h - 1), cx = min(max(ix, 0), d.w - 1);
+        const float* src = d.ptr + (size_t)cy * d.w + cx;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v[3 * r]) : "v"(src) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v[3 * r + 1]) : "v"(src + plane) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v[3 * r + 2]) : "v"(src + 2 * plane) : "memory");
+        okmask |= (ok ? 1u : 0u) << r;
+      }
+    } else {
+      const bf16_t* xb = x + (size_t)b * H * W * 4;
+#pragma unroll
+      for (int r = 0; r < FNLOAD; ++r) {
+        const int iy = iy0 + f_pr[r], ix = ix0 + f_pc[r];
+        const bool ok = ((f_in >> r) & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+        const bf16_t* src = xb + (cy * W + cx) * 4;
+        uint2 t;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t) : "v"(src) : "memory");
+        v[2 * r] = t.x; v[2 * r + 1] = t.y;
+        okmask |= (ok ? 1u : 0u) << r;
+      }
     }
   };
-  auto park = [&](const uint2 (&v)[FNLOAD], uint32_t okmask) {
+  auto park = [&](const unsigned (&v)[3 * FNLOAD], uint32_t okmask) {
 #pragma unroll
     for (int r = 0; r < FNLOAD; ++r) {
-      const uint2 t = ((okmask >> r) & 1u) ? v[r] : make_uint2(0u, 0u);
+      uint2 t = make_uint2(0u, 0u);
+      if ((okmask >> r) & 1u) {
+        if (RAW) {
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+          bf16x2 lo2;
+          lo2[0] = (bf16_t)((__uint_as_float(v[3 * r]) - raw.m0) * raw.is0);
+          lo2[1] = (bf16_t)((__uint_as_float(v[3 * r + 1]) - raw.m1) * raw.is1);
+          bf16x2 hi2;
+          hi2[0] = (bf16_t)((__uint_as_float(v[3 * r + 2]) - raw.m2) * raw.is2);
+          hi2[1] = (bf16_t)0.f;
+          t = make_uint2(__builtin_bit_cast(unsigned, lo2), __builtin_bit_cast(unsigned, hi2));
+        } else {
+          t = make_uint2(v[2 * r], v[2 * r + 1]);
+        }
+      }
       if ((f_in >> r) & 1u) *reinterpret_cast<uint2*>(patch + f_lds[r]) = t;
     }
   };
@@ -272,16 +317,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(wb[ks][j]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (RAW) __syncthreads();  // the image table is complete before the first fetch reads it
 
   const int g = gridDim.x;
   int nth = 0;
-  auto do_tile = [&](int tile, uint2 (&q)[FNLOAD], uint32_t& qm) {
-    // issued after this tile's patch loads (two tiles ago): 2 stores, the next tile's 6 loads, 2 stores -- all may stay in flight
+  auto do_tile = [&](int tile, unsigned (&q)[3 * FNLOAD], uint32_t& qm) {
+    // issued after this tile's patch loads (two tiles ago): 2 stores, the next tile's NV loads, 2 stores -- all may stay in flight
     // (the first two tiles have fewer operations behind their patch)
-    static_assert(FNLOAD == 6, "the vmcnt immediates below are FNLOAD (+ 2 stores per finished tile)");
-    if (nth == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (nth == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    static_assert(FNLOAD == 6, "the vmcnt immediates below are NV = 6 / 18 (+ 2 stores per finished tile)");
+    if (nth == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV) : "memory");
+    else if (nth == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV + 2) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NV + 4) : "memory");
     ++nth;
     park(q, qm);
     lds_barrier();
@@ -349,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
     lds_barrier();  // patch and stem tile are rewritten by the next tile
   };
 
-  uint2 qa[FNLOAD], qb[FNLOAD];
+  unsigned qa[3 * FNLOAD], qb[3 * FNLOAD];
   uint32_t ma, mb;
   int tile = blockIdx.x;
   fetch(tile, qa, ma);
@@ -368,8 +414,20 @@ int launch_stem_pool(const void* x, const void* wp, const float* scale, const fl
                      int H2, int W2, int H4, int W4, hipStream_t s) {
   const int tiles_y = (H4 + FPR - 1) / FPR, tiles_x = (W4 + FPC - 1) / FPC, ntiles = B * tiles_y * tiles_x;
   const int grid = ntiles < 512 ? ntiles : 512;  // 2 persistent blocks per CU
-  hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), FLDS, s, (const bf16_t*)x, (const bf16_t*)wp, scale, shift, (bf16_t*)out,
-                     (char*)trash, H, W, H2, W2, H4, W4, tiles_y, tiles_x, ntiles);
+  hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(256), FLDS, s, (const bf16_t*)x, StemRawArgs{}, (const bf16_t*)wp, scale, shift,
+                     (bf16_t*)out, (char*)trash, H, W, H2, W2, H4, W4, tiles_y, tiles_x, ntiles);
+  return (int)hipGetLastError();
+}
+
+// the same from the caller's raw images: imgs_dev[B] = (fp32 (3, h, w) planes, h, w), normalised with (p - mean) * (1 / std) on the way
+int launch_stem_pool_raw(const ImageDesc* imgs_dev, const float* mean, const float* stdv, const void* wp, const float* scale,
+                         const float* shift, void* out, void* trash, int B, int H, int W, int H2, int W2, int H4, int W4, hipStream_t s) {
+  if (B > STEM_RAW_MAX_BATCH) return -1;
+  const int tiles_y = (H4 + FPR - 1) / FPR, tiles_x = (W4 + FPC - 1) / FPC, ntiles = B * tiles_y * tiles_x;
+  const int grid = ntiles < 512 ? ntiles : 512;  // 2 persistent blocks per CU
+  const StemRawArgs raw{imgs_dev, B, mean[0], mean[1], mean[2], 1.f / stdv[0], 1.f / stdv[1], 1.f / stdv[2]};
+  hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(256), FLDS + (size_t)B * sizeof(ImageDesc), s, (const bf16_t*)nullptr, raw,
+                     (const bf16_t*)wp, scale, shift, (bf16_t*)out, (char*)trash, H, W, H2, W2, H4, W4, tiles_y, tiles_x, ntiles);
   return (int)hipGetLastError();
 }
 

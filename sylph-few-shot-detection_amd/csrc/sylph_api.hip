@@ -252,6 +252,9 @@ struct Plan {
   std::vector<OpFn> cls_logits_ops;  // the checkpoint's cls_logits conv on this plan's cls tower output (sylph_fcos_head_pretrained)
   const float* cls_logits_dst = nullptr;  // the logits buffer those ops were built for
   int cand_cap = 0, pool_cap = 0;
+  bool stem_takes_raw = false;  // this plan's first backbone op is the fused stem + pool kernel (bf16): it can read raw images
+  bool raw_input = false;     // the batch came in through sylph_preprocess and its normalisation is fused into the stem kernel
+                              // (launch_stem_pool_raw reads the caller's images through img_desc_dev): x0 has NOT been written
   bool scan_fused = false;    // the candidate buffers were filled by logits_scan_kernel (many-way head): decode skips its scan
   bool logits_stale = false;  // ... and the logits buffer was not written: sylph_export_head runs the unfused conv first
   float* bias_pad = nullptr;  // fp32 class biases of the last sylph_fcos_head: [0, cap) zero-padded to the packed code rows; [cap, 2 cap) the
@@ -971,9 +974,15 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
       if (fuse_pool) {
         void* trash = nullptr;
         RET(c->dalloc(&trash, (size_t)512 * 256 * 16));
+        const Plan* PP = P;
         ops.push_back([=](hipStream_t s) {
-          return timed_op(c, "stem_pool_kernel", fl, s, [=](hipStream_t st) { return launch_stem_pool(x0, wp, scl, shf, po, trash, B, H, W, H2, W2, H4, W4, st); });
+          return timed_op(c, "stem_pool_kernel", fl, s, [=](hipStream_t st) {
+            if (PP->raw_input)  // (p - mean) / std applied on the way into the stem's LDS patch: no normalised copy of the batch
+              return launch_stem_pool_raw(PP->img_desc_dev, c->cfg.pixel_mean, c->cfg.pixel_std, wp, scl, shf, po, trash, B, H, W, H2, W2, H4, W4, st);
+            return launch_stem_pool(x0, wp, scl, shf, po, trash, B, H, W, H2, W2, H4, W4, st);
+          });
         });
+        P->stem_takes_raw = B <= STEM_RAW_MAX_BATCH;
       } else {
         ops.push_back([=](hipStream_t s) {
           return timed_op(c, "stem_conv_kernel", fl, s, [=](hipStream_t st) { return launch_stem_conv(x0, wp, scl, shf, so, B, H, W, H2, W2, st); });
@@ -1868,8 +1877,11 @@ int sylph_preprocess(sylph_ctx* c, int B, const float* const* images, const int*
   }
   HIPCHK(hipMemcpyAsync(P->img_desc_dev, P->img_desc_host, sizeof(ImageDesc) * B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(P->img_desc_ev, c->stream));
-  KCHK(launch_preprocess(c->dt, P->img_desc_dev, P->x0, B, mh, mw, c->cfg.pixel_mean, c->cfg.pixel_std, c->stream),
-       "preprocess");
+  const char* fp = getenv("SYLPH_FUSE_PREPROCESS");  // read per call (tests compare the two paths in one process)
+  P->raw_input = (!fp || atoi(fp) != 0) && P->stem_takes_raw;
+  if (!P->raw_input)
+    KCHK(launch_preprocess(c->dt, P->img_desc_dev, P->x0, B, mh, mw, c->cfg.pixel_mean, c->cfg.pixel_std, c->stream),
+         "preprocess");
   c->cur = P;
   if (ph) *ph = mh;
   if (pw) *pw = mw;
@@ -1934,6 +1946,7 @@ int sylph_preprocess_u8(sylph_ctx* c, int B, const unsigned char* const* images,
   HIPCHK(hipMemcpyAsync(P->rz_desc_dev, P->rz_host, need, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(P->img_desc_ev, c->stream));
   const int* tab_dev = reinterpret_cast<const int*>(reinterpret_cast<const char*>(P->rz_desc_dev) + sizeof(ResizeDesc) * B);
+  P->raw_input = false;  // this pipeline writes the normalised batch itself
   KCHK(launch_resize_preprocess(c->dt, P->rz_desc_dev, tab_dev, P->x0, B, mh, mw, c->cfg.pixel_mean, c->cfg.pixel_std, rgb_input,
                                 c->stream), "resize_preprocess");
   c->cur = P;
@@ -1945,6 +1958,8 @@ int sylph_preprocess_u8(sylph_ctx* c, int B, const unsigned char* const* images,
 int sylph_export_input(sylph_ctx* c, float* out) {
   Plan* P = c->cur;
   if (!P || !P->x0) return fail("sylph_preprocess must be called first");
+  if (P->raw_input)  // the normalisation is fused into the stem kernel: x0 has not been written for this batch (raw_input stays set)
+    KCHK(launch_preprocess(c->dt, P->img_desc_dev, P->x0, P->B, P->H, P->W, c->cfg.pixel_mean, c->cfg.pixel_std, c->stream), "preprocess");
   KCHK(launch_export_input(c->dt, P->x0, out, P->B, P->H, P->W, c->stream), "export_input");
   return 0;
 }

@@ -614,6 +614,28 @@ def _assert_boxes(got, want, levels, what=""):
     assert (err <= tol).all(), f"{what} max box error {err.max():.4g} px; worst err/stride {(err / STRIDES[levels][:, None]).max():.3g}"
 
 
+def test_normalisation_fused_into_the_stem_is_bit_identical(full_sd, monkeypatch):
+    """bf16: sylph_preprocess leaves (x - mean) / std to the stem kernel (stem_pool_kernel<RAW>: fp32 planes -> normalised bf16 patch
+    in LDS).  Ragged image sizes (zero padding in NORMALISED space, per image), against the separate preprocess pass: the res2..res5
+    stage outputs and the pyramid must be bit-identical, and export_input still returns the normalised batch."""
+    from sylph_amd import synthetic as W
+    imgs = W.synthetic_images(3, 203, 333, seed=21)
+    imgs = [imgs[0], imgs[1][:, :170, :301].contiguous(), imgs[2][:, :, :257].contiguous()]
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("SYLPH_FUSE_PREPROCESS", knob)
+        eng = _engine("bf16", _cfg())
+        eng.load_state_dict(full_sd)
+        eng.preprocess(imgs)
+        eng.backbone()
+        outs.append(([t.clone() for t in eng.export_pyramid()], eng.export_input().clone()))
+        eng.close()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().max()) > 1.0
+
+
 def test_stem_and_maxpool_kernels_bf16_vs_torch():
     """stem_conv_kernel (7x7 s2 p3, Cin 3, bf16) and maxpool_kernel directly, on sizes with ragged 8 x 16 tiles."""
     g = torch.Generator().manual_seed(11)

@@ -4,9 +4,9 @@
     python tools/rocpd_pmc.py <fetch.db> <write.db> <batch> [out.json]
 
 Sums the counters over the conv launches (conv_igemm / conv_hpipe / conv_pw / bottleneck64[p] / stem_pool / gn_logits / gn_taps + tap_gather) of the LAST query
-step (from the last preprocess_kernel dispatch on); also reports the sum over EVERY kernel of that step.  Units/corrections as MI355X_MICROARCH.md prescribes: the counters are
+step (from its first kernel on: preprocess_kernel, or stem_pool_kernel when the normalisation is fused into it); also reports the sum over EVERY kernel of that step.  Units/corrections as MI355X_MICROARCH.md prescribes: the counters are
 KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
-used as is (checked here against preprocess_kernel, whose write volume is known exactly)."""
+used as is (checked here against the step's first kernel, whose write volume is known exactly)."""
 import json
 import sqlite3
 import sys
@@ -16,7 +16,9 @@ def last_step(dbfile, counter):
     db = sqlite3.connect(dbfile)
     rows = db.execute("select kernel_name, value, start from counters_collection where counter_name=? order by start",
                       (counter,)).fetchall()
-    idx = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]][-1]
+    # a query step starts with preprocess_kernel, or -- bf16, normalisation fused into the stem -- with stem_pool_kernel
+    first = [i for i, r in enumerate(rows) if "preprocess_kernel" in r[0]] or [i for i, r in enumerate(rows) if "stem_pool_kernel" in r[0]]
+    idx = first[-1]
     step = rows[idx:]
     # every launch bench.py times as conv work (sylph_profile_*): the conv kernels proper and the fused passes that replace convs
     CONV = ("conv_igemm_kernel", "conv_hpipe_kernel", "conv_pw_kernel", "bottleneck64", "stem_pool_kernel", "stem_conv_kernel", "gn_logits_kernel",
@@ -41,8 +43,10 @@ out = {
     "hbm_bytes_per_launch": (2.0 * fetch + write) / n1,
     "all_kernels_hbm_bytes_per_image": (2.0 * fetch_all + write_all) / B,
     "per_kernel_hbm_bytes_per_image": {k: round((2.0 * fetch_by.get(k, 0.0) + write_by.get(k, 0.0)) / B) for k in sorted(set(fetch_by) | set(write_by))},
-    "calibration": {"preprocess_write_bytes": pre_w, "preprocess_write_expected": B * 800 * 1344 * 4 * 2,
-                    "preprocess_fetch_bytes_raw": pre_f, "preprocess_fetch_expected": B * 3 * 800 * 1333 * 4},
+    # first kernel of the step: preprocess_kernel writes B x 800 x 1344 x 4 bf16, the fused stem + pool kernel B x 200 x 336 x 64 bf16
+    # (the same byte count) and both read the B x 3 x 800 x 1333 fp32 input (the stem re-reads its tile halos: > expected)
+    "calibration": {"first_kernel_write_bytes": pre_w, "first_kernel_write_expected": B * 800 * 1344 * 4 * 2,
+                    "first_kernel_fetch_bytes_raw": pre_f, "first_kernel_fetch_expected": B * 3 * 800 * 1333 * 4},
     "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncorrected",
 }
 print(json.dumps(out, indent=1))

@@ -8,6 +8,8 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if "preprocess" in r[0]]
+if not idx:  # the normalisation is fused into the stem kernel: a step starts with it
+    idx = [i for i, r in enumerate(rows) if "stem_pool" in r[0]]
 step = rows[idx[-1]:]
 t0 = step[0][1]
 for n, s, e, g, wg in step:
