@@ -47,7 +47,9 @@ out = {
     # (the same byte count) and both read the B x 3 x 800 x 1333 fp32 input (the stem re-reads its tile halos: > expected)
     "calibration": {"first_kernel_write_bytes": pre_w, "first_kernel_write_expected": B * 800 * 1344 * 4 * 2,
                     "first_kernel_fetch_bytes_raw": pre_f, "first_kernel_fetch_expected": B * 3 * 800 * 1333 * 4},
-    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncorrected",
+    "note": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncorrected.  The fused stem reads its fp32 input with 4-byte loads: "
+            "its raw FETCH_SIZE already matches the expected bytes x the tile-halo overlap (see calibration), so the doubled per-kernel figure overstates it (~16 MB/img); "
+            "its writes include one 16-byte trash store per thread and tile (constant store count for the vmcnt bookkeeping)",
 }
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 4:
