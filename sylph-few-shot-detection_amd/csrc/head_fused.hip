@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void gn_logits_kernel(const bf16_t* __restrict
       float* op = out + grow * out_ld + 4 * lh;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(op + 8 * q) =
-            make_float4(acc[4 * q] + bs[4 * q], acc[4 * q + 1] + bs[4 * q + 1], acc[4 * q + 2] + bs[4 * q + 2], acc[4 * q + 3] + bs[4 * q + 3]);
+        if (8 * q + 4 * lh < out_ld)  // out_ld: any multiple of 4 >= N (8 for <= 8 classes)
+          *reinterpret_cast<float4*>(op + 8 * q) =
+              make_float4(acc[4 * q] + bs[4 * q], acc[4 * q + 1] + bs[4 * q + 1], acc[4 * q + 2] + bs[4 * q + 2], acc[4 * q + 3] + bs[4 * q + 3]);
     }
   }
 }
@@ -275,10 +276,10 @@ int launch_gn_pred_taps(const void* x, int ld, const float2* coef, const void* w
 }
 
 // x: raw (un-normalised) tower output [rows][ld] bf16; coef: [segments][256] (a, b); w: [32][256] bf16 (rows >= N zero);
-// out: fp32 [rows][out_ld >= 32]; segs / tiles: the 128-row pointwise tile table of the head
+// out: fp32 [rows][out_ld], out_ld a multiple of 4 >= N; segs / tiles: the 128-row pointwise tile table of the head
 int launch_gn_logits(const void* x, int ld, const float2* coef, const void* w, const float* bias, int N, float* out, int out_ld,
                      const SegDesc* segs, const int2* tiles, int n_tiles, hipStream_t s) {
-  if (N > 32 || out_ld < 32 || n_tiles <= 0) return -1;
+  if (N > 32 || out_ld < N || (out_ld & 3) != 0 || n_tiles <= 0) return -1;
   const int want = n_tiles;  // one block = 4 row groups = one 128-row tile per sweep
   const int grid = want < 2048 ? want : 2048;
   hipLaunchKernelGGL(gn_logits_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ld, coef, (const bf16_t*)w, bias, N, out, out_ld,
