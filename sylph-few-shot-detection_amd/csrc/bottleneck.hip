@@ -86,7 +86,7 @@ constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 //                     identity block is limited by the halo round trip, 0.80 ms of compute in 1.29 ms).  MFMA work per position is
 //                     the same (P1 recomputes 128 / 64 halo rows per position instead of 192 / 120, P2 / P3 run full 64 / 64 tiles
 //                     instead of 120 / 128), but 2.2 x as many tiles pay the per-tile fixed costs: measured 1.56 ms vs 1.31 ms per
-//                     launch at B = 64.  Parity-clean, kept behind SYLPH_BK_SMALL=1 for A/B runs; NOT the default.
+//                     launch at B = 64.  Parity-clean, kept behind SYLPH_BK_SMALL=1 in -DSYLPH_ABLATE builds for A/B runs; NOT the default.
 template <int NR1, int NR2, int NR3, bool DB>
 __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckArgs a) {
   constexpr int XR = NR1 * 64;                     // halo rows of a buffer
@@ -740,7 +740,9 @@ int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
   static_assert(lds_big == LDS_BYTES && lds_small <= 160 * 1024, "LDS budget");
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)bottleneck64_kernel<3, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big) != hipSuccess) return -7;
+#ifdef SYLPH_ABLATE
     if (hipFuncSetAttribute((const void*)bottleneck64_kernel<2, 1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small) != hipSuccess) return -7;
+#endif
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -750,8 +752,12 @@ int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
   // the tile walk pairs blockIdx & 7 (XCD) with blockIdx >> 3: the grid must be a whole number of 8-block rounds
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
-  if (small) hipLaunchKernelGGL((bottleneck64_kernel<2, 1, 2, true>), dim3(grid), dim3(256), lds_small, s, a);
-  else hipLaunchKernelGGL((bottleneck64_kernel<3, 2, 4, false>), dim3(grid), dim3(256), lds_big, s, a);
+#ifdef SYLPH_ABLATE
+  if (small) { hipLaunchKernelGGL((bottleneck64_kernel<2, 1, 2, true>), dim3(grid), dim3(256), lds_small, s, a); return (int)hipGetLastError(); }
+#else
+  if (small) return -1;  // the 64-position variant is an A/B build only
+#endif
+  hipLaunchKernelGGL((bottleneck64_kernel<3, 2, 4, false>), dim3(grid), dim3(256), lds_big, s, a);
   return (int)hipGetLastError();
 }
 

@@ -7,6 +7,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// A/B knobs of variants that were measured and rejected exist only in builds made with -DSYLPH_ABLATE
+// (tools/build_variant.sh): the product library reads no environment for them and carries no instantiation of them.
+#ifdef SYLPH_ABLATE
+#include <stdlib.h>
+#define SYLPH_AB_ENV(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define SYLPH_AB_ENV(name, dflt) (dflt)
+#endif
+
 namespace sylph {
 
 typedef __bf16 bf16_t;

@@ -613,13 +613,20 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-static int g_nbuf = 1;
+#ifdef SYLPH_ABLATE
+static int g_nbuf = 1;  // A/B knob: a second LDS stage (rejected)
 void conv_set_nbuf(int n) { g_nbuf = n == 2 ? 2 : 1; }
+#else
+static constexpr int g_nbuf = 1;
+void conv_set_nbuf(int) {}
+#endif
 
 template <typename T, typename OutT, int NBUF, bool FAST>
 static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
+#ifdef SYLPH_ABLATE  // reachable only through SYLPH_CONV_FORCE_BM / _BN
   if (BM == 256 && BN == 128) return launch_cfg<T, OutT, 256, 128, 2, 2, NBUF, FAST>(a, s);
   if (BM == 128 && BN == 256) return launch_cfg<T, OutT, 128, 256, 2, 2, NBUF, FAST>(a, s);
+#endif
   if (BM == 128 && BN == 128) return launch_cfg<T, OutT, 128, 128, 2, 2, NBUF, FAST>(a, s);
   if (BM == 128 && BN == 64) return launch_cfg<T, OutT, 128, 64, 2, 2, NBUF, FAST>(a, s);
   if (BM == 128 && BN == 32) return launch_cfg<T, OutT, 128, 32, 4, 1, NBUF, FAST>(a, s);
@@ -630,14 +637,17 @@ static int launch_n(const ConvArgs& a, int BM, int BN, hipStream_t s) {
 
 // FAST epilogue: see the kernel.  Only the production dtype (bf16 in, bf16 out, single stage) gets it.
 static bool fast_ok(const ConvArgs& a, int BN) {
-  static const int on = getenv("SYLPH_CONV_FAST") ? atoi(getenv("SYLPH_CONV_FAST")) : 1;
+  static const int on = SYLPH_AB_ENV("SYLPH_CONV_FAST", 1);
   return on && a.ss_padded_host && (BN > 64 || a.ss_padded) && a.Cout % BN == 0 && (a.out_ld & 7) == 0 && (a.res_mode == 0 || (a.res_ld & 7) == 0) &&
          a.mul_nch == 0 && (a.relu_nch == 0 || a.relu_nch >= a.Cout);
 }
 
 template <typename T, typename OutT>
 static int launch_t(const ConvArgs& a, int BM, int BN, hipStream_t s) {
-  return g_nbuf == 2 ? launch_n<T, OutT, 2, false>(a, BM, BN, s) : launch_n<T, OutT, 1, false>(a, BM, BN, s);
+#ifdef SYLPH_ABLATE
+  if (g_nbuf == 2) return launch_n<T, OutT, 2, false>(a, BM, BN, s);
+#endif
+  return launch_n<T, OutT, 1, false>(a, BM, BN, s);
 }
 
 // Tile choice: widest N tile the layer fills (MFMA-bound 3x3 convs); HBM-bound pointwise convs
@@ -647,19 +657,23 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
   int bn = cout >= 128 ? 128 : (cout > 32 ? 64 : 32);
   // (pointwise convs used to prefer 128x64 for occupancy; since the per-tile instruction diet 128x128 is equal or
   // better on every bottleneck 1x1: less LDS-DMA traffic per flop)
+#ifdef SYLPH_ABLATE
   if (const char* f = getenv("SYLPH_CONV_FORCE_BN")) {  // tuning knob
     const int v = atoi(f);
     if ((v == 64 || v == 128 || v == 256) && cout % v == 0) bn = v;
   }
+#endif
   int bm = 128;
   if (bn != 32) {
     const long blocks128 = (long)((rows_total + 127) / 128) * ((cout + bn - 1) / bn);
     if (blocks128 < 1024) bm = 64;
   }
+#ifdef SYLPH_ABLATE
   if (const char* f = getenv("SYLPH_CONV_FORCE_BM")) {  // tuning knob
     const int v = atoi(f);
     if ((v == 64 || v == 128 || v == 256) && bn != 32) bm = v;
   }
+#endif
   if (bn == 256) bm = 128;
   if (bm == 256 && bn != 128) bm = 128;
   *BM = bm;
@@ -669,8 +683,8 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hipStream_t s) {
   ConvArgs a = a_in;
   // stage the residual through LDS on the narrow (HBM-bound) tiles; measured 1.4 % slower (LDS occupancy 5 -> 4 blocks), so off; SYLPH_CONV_RES_LDS=1 enables
-  static const int res_lds_on = getenv("SYLPH_CONV_RES_LDS") ? atoi(getenv("SYLPH_CONV_RES_LDS")) : 0;
-  static const int ss_on = getenv("SYLPH_CONV_SS_LDS") ? atoi(getenv("SYLPH_CONV_SS_LDS")) : 1;
+  static const int res_lds_on = SYLPH_AB_ENV("SYLPH_CONV_RES_LDS", 0);
+  static const int ss_on = SYLPH_AB_ENV("SYLPH_CONV_SS_LDS", 1);
   a.res_lds = (res_lds_on && a.res_mode != 0 && BN == 64 && a.Cout % 64 == 0 && (a.res_ld & 7) == 0) ? 1 : 0;
   a.ss_padded_host = a.ss_padded;
   if (!ss_on || BN > 64) a.ss_padded = 0;  // the wide tiles are MFMA-bound and have no VGPRs to spare for the prefetch

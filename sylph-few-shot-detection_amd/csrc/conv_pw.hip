@@ -400,17 +400,19 @@ int launch_pw_pack_weights(const void* w, void* out, int Cout, int K, int BN, hi
 // Tile shape of a pointwise layer (false: not eligible): 128 x 256 (256 x 128 when Cout % 256 != 0), 3 ring stages -- the operand
 // ratio of conv_hpipe (12 fragment reads per 16 MFMAs) and 6 LDS-DMA instructions per wave and phase.  The 128 x 128 / 4-stage
 // variant (whole residual tile prefetched at the tile start, three activation phases in flight) is kept for A/B runs
-// (SYLPH_PW_TILE=1): measured 5-25 % slower on every layer of the R-50 graph -- per 32-channel phase a wave pays one barrier,
+// (SYLPH_PW_TILE=1, -DSYLPH_ABLATE builds only): measured 5-25 % slower on every layer of the R-50 graph -- per 32-channel phase a wave pays one barrier,
 // one counted wait and its LDS-DMA issue slots (~100 cycles each) for only 8 MFMAs.  SYLPH_PW_TILE=3: 256 x 256 tile, 8 lock-step
 // waves, one block per CU (A/B only: equal to the default within 3 %).
 bool conv_pw_tile(int cout, int k_total, bool has_res, int* BM, int* BN) {
-  static const int force = getenv("SYLPH_PW_TILE") ? atoi(getenv("SYLPH_PW_TILE")) : 0;
   if (cout % 128 != 0) return false;
   (void)k_total; (void)has_res;
-  const bool large = force != 1;
+#ifdef SYLPH_ABLATE
+  static const int force = SYLPH_AB_ENV("SYLPH_PW_TILE", 0);
   if (force == 3 && cout % 256 == 0) { *BM = 256; *BN = 256; return true; }  // experiment: 256 x 256 tile, 8 waves, one block per CU
-  if (large) { *BN = cout % 256 == 0 ? 256 : 128; *BM = 384 - *BN; }
-  else { *BM = 128; *BN = 128; }
+  if (force == 1) { *BM = 128; *BN = 128; return true; }
+#endif
+  *BN = cout % 256 == 0 ? 256 : 128;
+  *BM = 384 - *BN;
   return true;
 }
 
@@ -459,7 +461,8 @@ int launch_conv_pw(const ConvArgs& a_in, int BM, int BN, hipStream_t s) {
   int grid = (2 * n_cu + 7) & ~7;
   const long need = ((tiles + 7) / 8) * 8;
   if (need < grid) grid = (int)need;
-  static const int nst = getenv("SYLPH_PW_NST") ? atoi(getenv("SYLPH_PW_NST")) : 4;  // tuning knob: ring depth of the small tile
+#ifdef SYLPH_ABLATE
+  static const int nst = SYLPH_AB_ENV("SYLPH_PW_NST", 4);  // tuning knob: ring depth of the small tile
   if (BM == 128 && BN == 128) {
     if (nst == 3) { grid = (int)((3L * n_cu + 7) & ~7L); if (need < grid) grid = (int)need; return launch_pw_t<128, 128, 3>(a, grid, s); }
     return launch_pw_t<128, 128, 4>(a, grid, s);
@@ -469,6 +472,7 @@ int launch_conv_pw(const ConvArgs& a_in, int BM, int BN, hipStream_t s) {
     if (need < grid) grid = (int)need;
     return launch_pw_t<256, 256, 3, 8>(a, grid, s);
   }
+#endif
   if (BM == 128 && BN == 256) return launch_pw_t<128, 256, 3>(a, grid, s);
   if (BM == 256 && BN == 128) return launch_pw_t<256, 128, 3>(a, grid, s);
   return -1;

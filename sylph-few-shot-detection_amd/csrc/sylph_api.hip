@@ -535,7 +535,7 @@ static void set_patch(SegDesc* s, int ph, int pw, int xpad) {
 // padded to an even length with an empty patch (conv_halo_pipe.hip works on two patches per block).
 static int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g) {
   std::vector<int2> tiles;
-  static const int fixed = getenv("SYLPH_CONV_PATCH_8X16") ? atoi(getenv("SYLPH_CONV_PATCH_8X16")) : 0;  // A/B knob: the round-1 geometry
+  static const int fixed = SYLPH_AB_ENV("SYLPH_CONV_PATCH_8X16", 0);  // A/B knob (-DSYLPH_ABLATE builds): the round-1 geometry
   for (size_t s = 0; s < segs.size(); ++s) {
     int ph, pw;
     if (fixed) { ph = max_pos / 16; pw = 16; }
@@ -904,7 +904,7 @@ static int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx:
     // double-buffered and prefetched a whole tile ahead (bottleneck.hip <2, 1, 2, true>).  Measured 1.56 ms vs 1.31 ms per launch at
     // B = 64: the halo round trip is hidden, but 2.2 x as many tiles pay the per-tile fixed costs (five barriers, three pipeline
     // fills / MFMA drains, descriptor and address set-up: ~2.3 us per tile) -- the <= 128-position geometry stays the default.
-    static const int bk_small_on = getenv("SYLPH_BK_SMALL") ? atoi(getenv("SYLPH_BK_SMALL")) : 0;
+    static const int bk_small_on = SYLPH_AB_ENV("SYLPH_BK_SMALL", 0);
     const int bk_small = fuse_id && bk_small_on;
     if (bk_small) pick_patch(Hin, Win, 64, 128, 2, &ph, &pw);
     else pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
@@ -1520,7 +1520,7 @@ int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out) {
   c->device = device_id;
   c->dt = dtype == SYLPH_BF16 ? DT_BF16 : DT_F32;
   sylph_config_default(&c->cfg);
-  if (const char* nb = getenv("SYLPH_CONV_NBUF")) conv_set_nbuf(atoi(nb));  // tuning knob: LDS stages of the conv kernel
+  conv_set_nbuf(SYLPH_AB_ENV("SYLPH_CONV_NBUF", 1));  // A/B knob (-DSYLPH_ABLATE builds): LDS stages of the conv kernel
   if (const char* mp = getenv("SYLPH_MAX_PLANS")) c->max_plans = atoi(mp) > 1 ? (size_t)atoi(mp) : 2;
   {
     size_t free_b = 0, total_b = 0;
@@ -1667,10 +1667,10 @@ int sylph_finalize_weights(sylph_ctx* c) {
       RET(make_conv_bias(c, {hp + ".bbox_tower." + std::to_string(3 * i)}, &c->box_tower[i]));
       RET(make_gn(c, hp + ".bbox_tower." + std::to_string(3 * i + 1), &c->box_gn[i]));
     }
-    const char* pz = getenv("SYLPH_PAIR_TOWERS");
+    const int pair_on = SYLPH_AB_ENV("SYLPH_PAIR_TOWERS", 0);  // A/B knob (-DSYLPH_ABLATE builds only)
     // Pairing (both towers as ONE grouped launch per layer) paid +2 % with the pre-halo kernel (the A tile was shared by
     // four N tiles); with halo tiles the separate towers are 1 % faster (1 666-1 672 vs 1 645-1 660 img/s), so it is opt-in.
-    if (c->cfg.num_cls_convs == c->cfg.num_box_convs && c->cfg.num_cls_convs > 0 && (pz && atoi(pz) == 1)) {
+    if (c->cfg.num_cls_convs == c->cfg.num_box_convs && c->cfg.num_cls_convs > 0 && pair_on == 1) {
       // run both towers as ONE launch per layer: outputs side by side ([rows][512] = cls | bbox)
       const int n = c->cfg.num_cls_convs;
       c->pair_tower.resize(n); c->pair_gn.resize(n);
@@ -2233,6 +2233,7 @@ int sylph_codegen_classes(sylph_ctx* c, const float* boxes, int shots, float* co
   if (!P) return fail("no current batch");
   if (!boxes || !codes_out) return fail("NULL argument");
   if (shots < 1 || P->B % shots != 0) return fail("pooled_features.shape[0] " + std::to_string(P->B) + " Vs batch_size * num_shots: the batch is not a whole number of classes");
+  if (shots > 64) return fail("codegen: " + std::to_string(shots) + " shots per class in one call; the shot reduction handles at most 64 (chunk the class and reduce the chunk codes, sylph_reduce_codes)");
   OwnerScope own(c, P);
   if (c->cfg.cg_type == 1) BUILD(build_support_roienc(c, P), P);
   else BUILD(build_support(c, P), P);

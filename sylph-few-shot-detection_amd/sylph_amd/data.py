@@ -23,6 +23,7 @@ class SyntheticSupportSetLoader:
     def __init__(self, num_classes: int, shots: int, height: int, width: int, device="cuda", seed: int = 0,
                  shard: bool = True):
         self.ids = list(range(*inference_shard(num_classes))) if shard else list(range(num_classes))
+        self.num_items = num_classes  # over ALL ranks: what the code gather sizes its per-rank block from (no count exchange)
         self.shots, self.h, self.w, self.device, self.seed = shots, height, width, device, seed
 
     def __len__(self):
@@ -52,6 +53,7 @@ class SyntheticQueryLoader:
     def __init__(self, num_images: int, height: int, width: int, batch_size: int = 1, device="cuda", seed: int = 1,
                  shard: bool = True):
         self.ids = list(range(*inference_shard(num_images))) if shard else list(range(num_images))
+        self.num_items = num_images
         self.h, self.w, self.bs, self.device, self.seed = height, width, batch_size, device, seed
 
     def __len__(self):
@@ -75,6 +77,7 @@ class SyntheticBaseSupportLoader:
         for c, total in enumerate(shots_per_class):
             for s0 in range(0, total, chunk):
                 self.items.append((c, s0, min(chunk, total - s0), total))
+        self.num_items = len(self.items)
         lo, hi = inference_shard(len(self.items)) if shard else (0, len(self.items))
         self.items = self.items[lo:hi]
         self.h, self.w, self.device, self.seed = height, width, device, seed

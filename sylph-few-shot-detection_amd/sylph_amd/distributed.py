@@ -10,7 +10,8 @@ fp32 block per rank and ONE collective (all_gather_into_tensor): no pickle, no c
 host read-back.  Row layout (ROW = 280 floats = 1120 B):
 
     [0, 256) cls_conv | 256 cls_bias | 257 acc_weight | 258 class id | 259 valid | 260 cls_weight_norm |
-    261 has_weight_norm | 262-263 pad | [264, 280) class name, 64 raw UTF-8 bytes
+    261 has_weight_norm | 262 has_acc_weight (the record carried an "acc_weight" key) | 263 pad |
+    [264, 280) class name: 16 lanes x 3 UTF-8 bytes (longer names are cut at a character boundary, with a warning)
 
 Every rank contributes a block of the same, statically known capacity (the InferenceSampler shard size
 ceil(n / world), or num_classes rows indexed by class id for the base-class path); unused rows have
@@ -19,12 +20,14 @@ equal-size blocks is the right shape for the point-to-point xGMI fabric (no ring
 """
 from typing import List, Optional, Sequence, Tuple
 
+import warnings
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 CODE_DIM = 256
-F_BIAS, F_ACC, F_CID, F_VALID, F_WNORM, F_HAS_WNORM, F_NAME, NAME_FLOATS = 256, 257, 258, 259, 260, 261, 264, 16
+F_BIAS, F_ACC, F_CID, F_VALID, F_WNORM, F_HAS_WNORM, F_HAS_ACC, F_NAME, NAME_FLOATS = 256, 257, 258, 259, 260, 261, 262, 264, 16
 ROW = F_NAME + NAME_FLOATS
 NAME_BYTES = 3 * NAME_FLOATS  # 3 name bytes per fp32 lane (exact integers < 2^24)
 
@@ -60,7 +63,12 @@ def _name_floats(names: Optional[Sequence[Optional[str]]], n: int) -> torch.Tens
         for i, s in enumerate(names):
             if s:
                 b = str(s).encode("utf-8")
-                assert len(b) <= NAME_BYTES, f"class name {s!r} is longer than {NAME_BYTES} bytes"
+                if len(b) > NAME_BYTES:
+                    # never raise here: this runs on ONE rank right before a collective, and an exception would leave the other
+                    # ranks waiting in all_gather_into_tensor.  Cut at a character boundary and say so.
+                    cut = b[:NAME_BYTES].decode("utf-8", "ignore").encode("utf-8")
+                    warnings.warn(f"class name {s!r} is longer than {NAME_BYTES} bytes; it travels as {cut.decode('utf-8')!r}")
+                    b = cut
                 pad = b + b"\0" * (3 * NAME_FLOATS - len(b))
                 arr = np.frombuffer(pad, dtype=np.uint8).reshape(NAME_FLOATS, 3).astype(np.uint32)
                 vals[i] = (arr[:, 0] | (arr[:, 1] << 8) | (arr[:, 2] << 16)).astype(np.float32)
@@ -68,7 +76,7 @@ def _name_floats(names: Optional[Sequence[Optional[str]]], n: int) -> torch.Tens
 
 
 def pack_codes(cls_conv: torch.Tensor, cls_bias: torch.Tensor, class_ids, acc_weight=None, weight_norm=None,
-               names: Optional[Sequence[Optional[str]]] = None) -> torch.Tensor:
+               names: Optional[Sequence[Optional[str]]] = None, has_acc=None) -> torch.Tensor:
     """(n,256[,1,1]), (n,), ids -> (n, ROW) fp32 rows (layout above) on the device of cls_conv."""
     n = cls_conv.shape[0]
     dev = cls_conv.device
@@ -78,6 +86,9 @@ def pack_codes(cls_conv: torch.Tensor, cls_bias: torch.Tensor, class_ids, acc_we
     out[:, :CODE_DIM] = cls_conv.reshape(n, CODE_DIM)
     out[:, F_BIAS] = cls_bias.reshape(n)
     out[:, F_ACC] = 1.0 if acc_weight is None else torch.as_tensor(acc_weight, dtype=torch.float32, device=dev)
+    if has_acc is None:
+        has_acc = acc_weight is not None
+    out[:, F_HAS_ACC] = torch.as_tensor(has_acc, dtype=torch.float32, device=dev)  # explicit flag: a weight of exactly 1.0 is still a weight
     out[:, F_CID] = torch.as_tensor(class_ids, dtype=torch.float32, device=dev)
     out[:, F_VALID] = 1.0
     if weight_norm is not None:
@@ -179,5 +190,5 @@ def reduce_packed_codes(rows: torch.Tensor, divide_by_acc: bool = True) -> torch
         out[j, F_ACC] = 1.0 if divide_by_acc else acc[j]
         out[j, F_CID] = float(c)
         out[j, F_VALID] = 1.0
-        out[j, F_NAME:] = rows[first[j], F_NAME:]
+        out[j, F_HAS_ACC:] = rows[first[j], F_HAS_ACC:]  # flag + name lanes of the class's first row (as sylph_reduce_codes)
     return out

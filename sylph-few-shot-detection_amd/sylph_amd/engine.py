@@ -165,6 +165,7 @@ class Engine:
         self._batch = None  # (B, H, W, [(h,w)...])
         self._ncls = 0
         self._keep = []  # tensors that must outlive queued kernels
+        self._lib_writes = 0  # in-place writes into caller tensors through raw pointers (part of the class-code cache key)
 
     def close(self):
         if self._ctx:
@@ -199,6 +200,7 @@ class Engine:
             check(self.L.sylph_load_weight(self._ctx, k.encode(), c_void_p(t.data_ptr()), shape, max(t.dim(), 1)),
                   f"load_weight({k})")
         check(self.L.sylph_finalize_weights(self._ctx), "finalize_weights")
+        self._codes_key = None  # packed class codes depend on the checkpoint's CondConvBlock scales: never reuse across a reload
 
     # ---- query / support image path ----------------------------------------------------------------
     def level_shapes(self, H: int, W: int) -> List[Tuple[int, int]]:
@@ -283,7 +285,10 @@ class Engine:
         assert cls_conv.size(2) == 1 and cls_conv.size(3) == 1
         # The codes of an episode are the same tensors for every query batch: their packed fp32 form is kept (no cast / reshape /
         # scale kernels in the steady-state step) until a different tensor, or a modified one, arrives.
-        key = (id(cls_conv), cls_conv._version, id(cls_bias), None if cls_bias is None else cls_bias._version, bool(raw))
+        # Writes the library does through raw pointers (normalize_codes in place, ...) do not bump tensor._version: the engine
+        # counts them (_lib_writes) and the count is part of the key, as are the CondConvBlock scales.
+        key = (id(cls_conv), cls_conv._version, id(cls_bias), None if cls_bias is None else cls_bias._version, bool(raw),
+               tuple(self.cond_scales), self._cond_scales_loaded, self._lib_writes)
         cached = getattr(self, "_codes_key", None) == key
         if not cached:
             k = cls_conv.size(1) // 256
@@ -427,6 +432,9 @@ class Engine:
         B = self._batch[0]
         bx = boxes.to(self.device, torch.float32).reshape(-1, 4).contiguous()
         assert bx.shape[0] == B, f"pooled_features.shape[0] {bx.shape[0]} Vs batch_size * num_shots {B}"
+        if B > 64:
+            raise ValueError(f"{B} support images of one class in one call: the code generator's shot reduction handles at most 64 "
+                             "(split the class into chunks and reduce them, as the base-class path does)")
         out = torch.empty(257, device=self.device)
         self._keep_boxes = bx
         check(self.L.sylph_codegen(self._ctx, _ptr(bx), _ptr(out)), "codegen")
@@ -439,6 +447,9 @@ class Engine:
         B = self._batch[0]
         bx = boxes.to(self.device, torch.float32).reshape(-1, 4).contiguous()
         assert bx.shape[0] == B and B % shots == 0, f"pooled_features.shape[0] {bx.shape[0]} Vs batch_size * num_shots {B}"
+        if shots > 64:
+            raise ValueError(f"{shots} shots per class in one call: the code generator's shot reduction handles at most 64 (split the "
+                             "class into chunks and reduce them, as the base-class path does)")
         out = torch.empty(B // shots, 257, device=self.device)
         self._keep_boxes = bx
         check(self.L.sylph_codegen_classes(self._ctx, _ptr(bx), int(shots), _ptr(out)), "codegen_classes")
@@ -459,6 +470,7 @@ class Engine:
             wn = weight_norm.to(self.device, torch.float32).reshape(-1).contiguous()
             assert wn.numel() == codes.shape[0]
         check(self.L.sylph_normalize_codes(self._ctx, _ptr(codes), codes.shape[0], _ptr(wn)), "normalize_codes")
+        self._lib_writes += 1  # `codes` changed in place without a torch version bump
         return codes
 
     def reduce_codes(self, rows: torch.Tensor, num_classes: int, divide_by_acc: bool = True) -> torch.Tensor:

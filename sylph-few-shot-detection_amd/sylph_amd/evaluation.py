@@ -60,6 +60,17 @@ def inference_normalization(model, codes: List[Dict[str, Any]]):
             model.train(True)
 
 
+def class_padded_hw(support_set, divisibility: int = 32):
+    """(H, W) one class's support images are padded to when the class runs alone (ImageList.from_tensors: the maximum over its
+    images, rounded up to the backbone's size divisibility)."""
+    d = int(divisibility)
+    if len(support_set) == 0:
+        return (0, 0)
+    h = max(int(rec["image"].shape[-2]) for rec in support_set)
+    w = max(int(rec["image"].shape[-1]) for rec in support_set)
+    return ((h + d - 1) // d * d, (w + d - 1) // d * d)
+
+
 def _log_totals(kind: str, unit: str, total_time: float, compute_time: float, n: int, devices: int):
     logger.info("Total inference time: {:.3f}s ({:.6f} s / {} per device, on {} devices)".format(
         total_time, total_time / max(n, 1), unit, devices))
@@ -85,7 +96,9 @@ def inference_on_support_set_dataset(model, data_loader, output_dir: str = None)
         stack.enter_context(torch.no_grad())
         # Classes are grouped into batches of up to SYLPH_SUPPORT_BATCH support images (default 64) that share the backbone and
         # code-generator launches (model.forward_class_codes); the loader still yields -- and the model API still accepts --
-        # one class per item, as in the reference.  SYLPH_SUPPORT_BATCH=0: one call per class.
+        # one class per item, as in the reference.  Only classes with the same shot count AND the same padded size (see
+        # class_padded_hw) share a batch, so every class sees exactly the tensors of its own one-class call.
+        # SYLPH_SUPPORT_BATCH=0: one call per class.
         cap = int(os.environ.get("SYLPH_SUPPORT_BATCH", "64"))
         batched = cap > 0 and hasattr(model, "forward_class_codes")
         group: List[Any] = []
@@ -117,8 +130,11 @@ def inference_on_support_set_dataset(model, data_loader, output_dir: str = None)
                 n_img = 0
                 start_time, compute = time.perf_counter(), 0.0
             k = len(inputs[0]["support_set"])
+            # A class may only join a group whose padded batch size equals the size the class would be padded to ALONE (the max
+            # over ALL of its support images, rounded up to the size divisibility): the reference pads one class per call
+            # (meta_one_stage_detector.py:229-254), and the activations next to the right / bottom border depend on that size.
             same = not group or (len(group[0][0]["support_set"]) == k and
-                                 group[0][0]["support_set"][0]["image"].shape == inputs[0]["support_set"][0]["image"].shape)
+                                 class_padded_hw(group[0][0]["support_set"]) == class_padded_hw(inputs[0]["support_set"]))
             if group and (not batched or not same or n_img + k > cap):
                 flush()
                 n_img = 0

@@ -289,12 +289,16 @@ class MetaOneStageDetector(nn.Module):
         """Support-path throughput: the reference (and forward_class_code above) runs ONE class per call; here several classes
         share the backbone / code-generator launches of one batch (B = classes x shots).  `items`: loader items, each a list of
         length 1 as in forward_class_code.  Falls back to one call per class when the shot counts differ (or are not the
-        ROIEncoder's EVAL_SHOT) or a record carries more than one box."""
+        ROIEncoder's EVAL_SHOT), a record carries more than one box, or the classes would be padded to different sizes when run
+        alone (the padded size decides the activations along the right / bottom border, hence the code)."""
         assert not self.training, "Not for training"
         recs = [[rec for x in it for rec in x["support_set"]] for it in items]
         shots = len(recs[0]) if recs else 0
+        from .evaluation import class_padded_hw
+        d = getattr(self.backbone, "size_divisibility", 32)
         batchable = (len(items) > 1 and hasattr(self.code_generator, "forward_classes") and shots > 0
                      and getattr(self.code_generator, "eval_shot", None) in (None, shots)
+                     and len({class_padded_hw(r, d) for r in recs if r}) == 1  # every class padded as in its own one-class call
                      and all(len(it) == 1 and len(r) == shots for it, r in zip(items, recs))
                      and all(len(rec["instances"].gt_boxes.tensor) == 1 for r in recs for rec in r))
         if not batchable:

@@ -462,6 +462,62 @@ def test_support_classes_batched_equal_one_class_per_call(sd, dtype):
         assert torch.equal(r["class_code"]["cls_conv"], b["cls_conv"].cpu())
 
 
+def _mixed_size_support_items(sizes_per_class, seed=5):
+    """Loader items (one class each) whose support images have the given (h, w) sizes; one box per image."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.structures import Boxes, Instances
+    items = []
+    for c, sizes in enumerate(sizes_per_class):
+        recs = []
+        for s, (h, w) in enumerate(sizes):
+            im = W.synthetic_images(1, h, w, seed=seed * 100 + c * 10 + s)[0]
+            inst = Instances((h, w))
+            inst.gt_boxes = Boxes(torch.tensor([[8.0 + c, 6.0 + s, 0.7 * w, 0.8 * h]]))
+            inst.gt_classes = torch.tensor([c])
+            recs.append({"image": im, "instances": inst, "height": h, "width": w})
+        items.append([{"support_set": recs, "support_set_target": torch.tensor(c), "class_name": f"class_{c}"}])
+    return items
+
+
+def test_support_batching_respects_per_class_padding(sd):
+    """with mixed image sizes a class may only share a batch with classes that are padded to the same (H, W) when run
+    alone (the reference pads ONE class per call, meta_one_stage_detector.py:229-254; the padded size decides the border
+    activations).  Classes of kind A pad to 128x160 (the FIRST image of the first one is 90x120, exactly the first image of a
+    kind-B class that pads to 96x128: the old first-image guard grouped those two).  fp32 codes must be bit-identical to one class per call, both
+    through forward_class_codes (falls back) and through the evaluation loop (groups only 2 + 3)."""
+    from sylph_amd.evaluation import class_padded_hw, inference_on_support_set_dataset
+    runner, cfg = _cfg()
+    m = runner.build_model(cfg, dtype="f32")
+    m.load_state_dict(sd)
+    m.eval()
+    A = [[(90, 120), (128, 150)], [(120, 160), (128, 130)], [(128, 160), (100, 100)]]  # pad to 128x160 (first image small / ragged)
+    Bs = [[(90, 120), (96, 128)], [(96, 100), (70, 128)]]  # pad to 96x128
+    sizes = [A[0], Bs[0], A[1], A[2], Bs[1], Bs[0], A[0], A[2]]
+    items = _mixed_size_support_items(sizes)
+    pads = [class_padded_hw(it[0]["support_set"]) for it in items]
+    assert pads == [(128, 160), (96, 128), (128, 160), (128, 160), (96, 128), (96, 128), (128, 160), (128, 160)]
+    one = [{k: v.clone() for k, v in m(it, run_type="meta_learn_test_support").items()} for it in items]
+    calls = []
+    orig = m.forward_class_codes
+
+    def spy(group):
+        calls.append(len(group))
+        return orig(group)
+
+    m.forward_class_codes = spy
+    many = orig(items)  # mixed padded sizes: must fall back to one call per class
+    for a, b in zip(one, many):
+        assert torch.equal(a["cls_conv"], b["cls_conv"]) and torch.equal(a["cls_bias"], b["cls_bias"])
+    grouped = inference_on_support_set_dataset(m, items)
+    # the loop flushes at every padded-size change (and once at the end of its 5 warm-up items): only (2, 3) and (6, 7) share a batch
+    assert calls == [2, 2], calls
+    for a, r in zip(one, grouped):
+        assert torch.equal(a["cls_conv"].cpu(), r["class_code"]["cls_conv"]) and torch.equal(a["cls_bias"].cpu(), r["class_code"]["cls_bias"])
+    same = orig([items[2], items[3], items[6]])  # equal padded sizes, ragged images inside: one shared batch, identical codes
+    for a, b in zip([one[2], one[3], one[6]], same):
+        assert torch.equal(a["cls_conv"], b["cls_conv"]) and torch.equal(a["cls_bias"], b["cls_bias"])
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_base_detector_with_3x3_cls_logits(sd, dtype):
     """MODEL.FCOS.CLS_LOGITS_KERNEL_SIZE = 3 (the adet-style classifier, fcos.py:418-427; Sylph's default_configs.py:48 switches it to 1):

@@ -221,8 +221,11 @@ def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
     assert rows[4:7, D.F_CID].tolist() == [4.0, 5.0, 6.0]
     assert D.unpack_names(rows[4:7]) == ["cat", "d\u00f6g", "x" * 48]
     assert torch.isfinite(rows).all() and (rows[:, D.F_NAME:] == rows[:, D.F_NAME:].round()).all()  # names travel as exact integers
-    with pytest.raises(AssertionError):
-        D.pack_codes(torch.randn(1, 256), torch.randn(1), [0], names=["y" * 49])  # no silent truncation
+    # an over-long name must not raise on one rank right before the collective (the others would hang): it is cut at a
+    # UTF-8 character boundary, loudly
+    with pytest.warns(UserWarning, match="longer than 48 bytes"):
+        long = D.pack_codes(torch.randn(1, 256), torch.randn(1), [0], names=["y" * 46 + "\u00f6\u00f6"])
+    assert D.unpack_names(long) == ["y" * 46 + "\u00f6"]
     by_id = D.scatter_by_class_id(rows, 8)
     assert by_id[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1, 1, 0] and torch.equal(by_id[5], rows[5])
     # a class id outside [0, num_classes) must not land on another class's slot
@@ -230,6 +233,98 @@ def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
     assert small[:, D.F_VALID].tolist() == [0, 0, 0, 0, 1, 1] and torch.equal(small[5], rows[5])
     with pytest.raises(AssertionError):
         D.order_by_class_id(rows, 6)
+
+
+def test_acc_weight_flag_lane_survives_weight_one():
+    """whether a record carries "acc_weight" travels in its own lane; a weight of exactly 1.0 keeps the key."""
+    from sylph_amd.runner import _codes_from_rows, _rows_from_codes
+    mk = lambda cid, acc: {"support_set_target": cid, "class_name": f"c{cid}", "class_code": dict(
+        {"cls_conv": torch.randn(1, 256, 1, 1), "cls_bias": torch.randn(1, 1, 1, 1)}, **({} if acc is None else {"acc_weight": acc}))}
+    codes = [mk(0, 1.0), mk(1, None), mk(2, 0.25)]
+    rows = _rows_from_codes(codes, torch.device("cpu"))
+    assert rows[:, D.F_HAS_ACC].tolist() == [1.0, 0.0, 1.0]
+    back = _codes_from_rows(rows, keep_acc=None)
+    assert ["acc_weight" in c["class_code"] for c in back] == [True, False, True]
+    assert back[0]["class_code"]["acc_weight"] == 1.0 and back[2]["class_code"]["acc_weight"] == 0.25
+    red = D.reduce_packed_codes(torch.cat([rows, rows[2:3]]), divide_by_acc=False)
+    assert red[:, D.F_HAS_ACC].tolist() == [1.0, 0.0, 1.0] and abs(float(red[2, D.F_ACC]) - 0.5) < 1e-7
+
+
+def test_multi_seed_multi_dataset_loop_mean_and_std():
+    """_do_test_meta_learning without explicit loaders = the reference's loop (meta_fcos_runner.py:451-672): seeds x datasets,
+    seeded support loaders, pretrained codes on "base" datasets, results[f"seed{s}"], mean over seeds in results[tag], AP_avg /
+    AP_std.  Host control flow only: the model is a stub that records the calls."""
+    from sylph_amd.runner import MetaFCOSRunner
+
+    class Loader(list):
+        num_items = 3
+
+    class Model:
+        device = torch.device("cpu")
+        calls = []
+
+        def __call__(self, batched_inputs=None, class_code=None, run_type=None):
+            Model.calls.append(run_type)
+            if run_type == "meta_learn_test_support":
+                return {"cls_conv": torch.ones(1, 256, 1, 1) * float(batched_inputs[0]["seed"]), "cls_bias": torch.zeros(1, 1, 1, 1)}
+            if run_type == "meta_learn_normalize_code":
+                return class_code
+            assert run_type == "meta_learn_test_instance"
+            if batched_inputs[0]["dataset"].endswith("base"):
+                assert class_code is None  # EVAL_WITH_PRETRAINED_CODE
+            else:
+                assert tuple(class_code["cls_conv"].shape) == (3, 256, 1, 1)
+            return [{"seed_seen": None if class_code is None else float(class_code["cls_conv"][0, 0, 0, 0])}]
+
+    class Ev:
+        def __init__(self, name):
+            self.name, self.vals = name, []
+
+        def reset(self):
+            self.vals = []
+
+        def process(self, inputs, outputs):
+            self.vals.append(outputs[0]["seed_seen"])
+
+        def evaluate(self):
+            s = self.vals[0]
+            ap = 40.0 if s is None else 10.0 + 2.0 * s
+            return {"bbox": {"AP": ap, "AP50": 2 * ap, "APr": ap - 1}}
+
+    class R(MetaFCOSRunner):
+        built = []
+
+        def build_episodic_learning_detection_test_support_set_loader(self, cfg, name, seed=0):
+            R.built.append(("support", name, seed))
+            return Loader([[{"support_set": [], "support_set_target": torch.tensor(c), "class_name": str(c), "seed": seed}]
+                           for c in range(3)])
+
+        def build_episodic_learning_detection_test_query_loader(self, cfg, name):
+            return [[{"dataset": name}]]
+
+        def get_evaluator(self, cfg, name, output_folder=None):
+            return Ev(name)
+
+    r = R()
+    cfg = r.get_default_cfg()
+    cfg.DATASETS.TEST = ("coco_meta_val_novel", "coco_meta_val_base")
+    cfg.TEST.REPEAT_TEST = 3
+    cfg.MODEL.META_LEARN.EVAL_WITH_PRETRAINED_CODE = True
+    cfg.MODEL.META_LEARN.USE_ALL_GTS_IN_BASE_CLASSES = False
+    cfg.MODEL.META_LEARN.EPISODIC_LEARNING = True
+    res = r.do_test(cfg, Model())
+    assert list(res) == ["default", "seed0", "seed1", "seed2"]
+    assert R.built == [("support", "coco_meta_val_novel", s) for s in range(3)]  # the base dataset ran on pretrained codes
+    novel = [res[f"seed{s}"]["coco_meta_val_novel"]["bbox"]["AP"] for s in range(3)]
+    assert novel == [10.0, 12.0, 14.0]
+    top = res["default"]["coco_meta_val_novel"]["bbox"]
+    assert abs(top["AP"] - 12.0) < 1e-9 and abs(top["AP50"] - 24.0) < 1e-9
+    assert abs(top["AP_avg"] - 12.0) < 1e-9 and abs(top["AP_std"] - np.std([10.0, 12.0, 14.0])) < 1e-9 and "APr_std" in top
+    base = res["default"]["coco_meta_val_base"]["bbox"]
+    assert abs(base["AP"] - 40.0) < 1e-9 and base["AP_std"] == 0.0
+    # a non-final iteration runs one seed only (meta_fcos_runner.py:476-478)
+    one = r._do_test_meta_learning(cfg, Model(), train_iter=10)
+    assert list(one) == ["default", "seed0"]
 
 
 def test_detections_to_coco_rows_batches_one_copy():
