@@ -184,6 +184,20 @@ int sylph_normalize_codes(sylph_ctx* ctx, float* codes_dev, int n, const float* 
 int sylph_reduce_codes(sylph_ctx* ctx, const float* rows_dev, int n, int row_ld, float* out_dev, int num_classes,
                        int divide_by_acc);
 
+/* The episode's one collective through the C ABI (MetaFCOSRunner._gather_class_code, sylph/runner/meta_fcos_runner.py:381-439,
+ * which pickles dicts through all_gather_object): local_dev (n_local, 280) packed class-code rows of this rank (row layout of
+ * sylph_reduce_codes + 16 name lanes) -> out_dev (world * capacity, 280): every rank's block in rank order on every rank, unused
+ * rows zero (valid = 0).  ONE in-place ncclAllGather of equal-size blocks on the context's stream (RCCL over xGMI); capacity is the
+ * statically known shard size ceil(n_classes / world), so there is no count exchange and no host read-back.  comm: an ncclComm_t --
+ * from sylph_comm_init_rank below or the host's own RCCL communicator.  librccl is resolved at first use (dlopen): the library has
+ * no link-time dependency on it.  The Python host side keeps torch.distributed (backend "nccl" = RCCL) as its default. */
+int sylph_allgather_codes(sylph_ctx* ctx, void* comm, const float* local_dev, int n_local, int capacity, float* out_dev);
+/* Communicator helpers for hosts without their own RCCL binding: rank 0 makes the 128-byte id (ncclGetUniqueId), hands it to the
+ * other ranks over any channel, every rank calls init_rank (ncclCommInitRank on the context's device). */
+int sylph_comm_unique_id(char* id_out_128);
+int sylph_comm_init_rank(sylph_ctx* ctx, const char* id_128, int nranks, int rank, void** comm_out);
+int sylph_comm_destroy(void* comm);
+
 /* Primitive entries used by the kernel parity tests (F.conv2d / F.group_norm equivalents).
  * x: (B,C,H,W) fp32 NCHW device; w_host: (Cout,Cin,KH,KW) fp32 host; scale/shift host (Cout) or NULL;
  * residual: (B,Cout,Ho,Wo) device or NULL; y: (B,Cout,Ho,Wo) fp32 device. */
@@ -222,6 +236,16 @@ int sylph_export_tower(sylph_ctx* ctx, int tower, int layer, int level, float* y
 int sylph_bottleneck(sylph_ctx* ctx, const float* x_nchw_dev, int B, int Cin, int H, int W, int stride, int mid, int cout,
                      const float* const* w_host, const float* const* scale_host, const float* const* shift_host,
                      float* y_nchw_dev);
+
+/* Kernel parity entry: TWO consecutive identity BottleneckBlocks (Cin == cout == C, stride 1) through the launches
+ * sylph_backbone_fpn uses for such a pair -- with C = 4 * mid, mid in {128, 256} (res3 / res4 shapes), bf16 and enough rows (or
+ * SYLPH_FUSE_DUAL=2) that is conv1, conv2, ONE dual-output launch (conv3 + residual + ReLU of block 0 and conv1 + ReLU of block 1,
+ * conv_dual.hip), conv2, conv3.  w_host[6] / scale_host[6] / shift_host[6]: conv1, conv2, conv3 of block 0, then of block 1.
+ * y_mid (may be NULL): block 0's output, y: block 1's output, both (B,C,H,W) fp32 NCHW device.
+ * (call site meta_one_stage_detector.py:181,273) */
+int sylph_bottleneck_pair(sylph_ctx* ctx, const float* x_nchw_dev, int B, int C, int H, int W, int mid,
+                          const float* const* w_host, const float* const* scale_host, const float* const* shift_host,
+                          float* y_mid_nchw_dev, float* y_nchw_dev);
 
 /* Kernel parity entry: one FPN lateral as sylph_backbone_fpn launches it (detectron2 FPN.forward: lateral 1x1 conv + bias, plus
  * the nearest-2x upsampled level above, fused as a residual; call site meta_one_stage_detector.py:181,273).  x (B,C,H,W) fp32 NCHW

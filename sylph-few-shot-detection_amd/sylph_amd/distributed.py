@@ -116,8 +116,62 @@ def pad_block(local: torch.Tensor, capacity: int) -> torch.Tensor:
     return block
 
 
+class CAbiCodeGather:
+    """The same collective WITHOUT torch.distributed on the data path: sylph_allgather_codes of libsylph_hip.so (one in-place
+    ncclAllGather on the engine's stream through the library's own RCCL communicator) -- what a non-Python host of the C ABI calls.
+    The 128-byte communicator id is made by rank 0 and must reach the other ranks over some side channel: `id_bytes` (e.g. from a
+    launcher), else one torch.distributed broadcast at construction.  Opt-in (install_c_abi_gather); torch.distributed (backend
+    "nccl" = RCCL) stays the default."""
+
+    def __init__(self, engine, rank: Optional[int] = None, world: Optional[int] = None, id_bytes: Optional[bytes] = None):
+        import ctypes
+        from ._lib import check
+        self.engine, self.L = engine, engine.L
+        self.rank = get_rank() if rank is None else int(rank)
+        self.world = get_world_size() if world is None else int(world)
+        if id_bytes is None:
+            buf = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                check(self.L.sylph_comm_unique_id(buf), "comm_unique_id")
+            box = [bytes(buf.raw)]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)  # bootstrap only: 128 bytes, once per process group
+            id_bytes = box[0]
+        assert len(id_bytes) == 128
+        self.comm = ctypes.c_void_p(0)
+        check(self.L.sylph_comm_init_rank(engine._ctx, id_bytes, self.world, self.rank, ctypes.byref(self.comm)), "comm_init_rank")
+
+    def gather(self, local: torch.Tensor, capacity: int) -> torch.Tensor:
+        """(n, ROW) device rows of this rank -> (world * capacity, ROW), rank order, unused rows zero."""
+        import ctypes
+        from ._lib import check
+        assert local.is_cuda and local.dtype == torch.float32 and local.dim() == 2 and local.shape[1] == ROW
+        local = local.contiguous()
+        self.engine._stream()
+        out = torch.empty(self.world * capacity, ROW, dtype=torch.float32, device=local.device)
+        check(self.L.sylph_allgather_codes(self.engine._ctx, self.comm, ctypes.c_void_p(local.data_ptr()), int(local.shape[0]),
+                                           int(capacity), ctypes.c_void_p(out.data_ptr())), "allgather_codes")
+        return out
+
+    def close(self):
+        if self.comm:
+            self.L.sylph_comm_destroy(self.comm)
+            self.comm = None
+
+
+_c_abi_gather: Optional[CAbiCodeGather] = None
+
+
+def install_c_abi_gather(g: Optional[CAbiCodeGather]):
+    """Route gather_packed_codes through the C-ABI collective (None: back to torch.distributed)."""
+    global _c_abi_gather
+    _c_abi_gather = g
+
+
 def gather_code_blocks(block: torch.Tensor) -> torch.Tensor:
     """ONE collective: every rank's (capacity, ROW) block -> (world * capacity, ROW) in rank order on every rank."""
+    if _c_abi_gather is not None and block.is_cuda:
+        return _c_abi_gather.gather(block, block.shape[0])
     if not (dist.is_available() and dist.is_initialized()):
         return block
     world = get_world_size()  # a single-rank group still goes through the collective (RCCL init + call are exercised)
@@ -131,6 +185,9 @@ def gather_packed_codes(local: torch.Tensor, capacity: Optional[int] = None) -> 
     host read-back; consumers select by the valid column).  capacity defaults to the local row count, which is only
     correct when every rank holds the same number of rows."""
     cap = int(capacity) if capacity is not None else max(int(local.shape[0]), 1)
+    if _c_abi_gather is not None and local.is_cuda:
+        assert local.shape[0] <= cap, f"{local.shape[0]} rows do not fit the gather block of {cap}"
+        return _c_abi_gather.gather(local, cap)  # pads inside the call (memset of the block tail on the stream)
     return gather_code_blocks(pad_block(local, cap))
 
 

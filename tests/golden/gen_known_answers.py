@@ -8,7 +8,9 @@ matmul, NMS as an O(n^2) suppression table), plus hand-derived expectations (lin
 form; the NMS / postprocess boxes are constructed so that IoUs and scaled coordinates are exact small rationals).
 The oracle (CPU tests) AND the HIP path (-m gpu tests, through the C ABI) are checked against these fixtures.
 
-    python tests/golden/gen_known_answers.py      # writes tests/golden/g8_known_answers.npz
+    python tests/golden/gen_known_answers.py      # writes tests/golden/g8_known_answers.npz and g8b_known_answers.npz
+    python tests/golden/gen_known_answers.py --only-b   # only the round-4 additions (g8b: level boundaries, degenerate / outside
+                                                        # boxes, integral adaptive bins; two-chunk NMS, reversed IoU == 0.6, ties, clipping)
 
 Reference call sites: sylph/modeling/code_generator/code_generator.py:341-348,928-930 (ROIPooler),
 sylph/modeling/meta_fcos/fcos_outputs.py:15,904-1028 (decode, ml_nms, top-k keep),
@@ -317,10 +319,179 @@ def gen_backbone(out):
     print("backbone: p3..p7", [p.shape for p in pyr], "max |p3|", float(np.abs(pyr[0]).max()))
 
 
+# ===================================================================================== round 4: wider third-party cases (g8b)
+ROI_CASES_B = [
+    # box, expected level (0-based pyramid index), closed form applies
+    ([8.0, 8.0, 120.0, 120.0], 0, True),            # sqrt(area) == 112: 4 + log2(0.5 + 1e-8) = 3.00000003 -> level 3 (the epsilon decides)
+    ([8.0, 8.0, 119.9, 119.9], 0, True),            # just below: floor(2.9987) = 2 -> clamped to 3
+    ([16.0, 16.0, 239.9, 239.9], 0, True),          # just below the canonical size
+    ([16.0, 16.0, 240.0, 240.0], 1, True),          # exactly the canonical size -> level 4
+    ([0.0, 0.0, 112.0, 112.0], 0, False),           # starts at the image corner: the first samples sit at -0.5 + ... < 0 and are clamped to 0
+    ([-96.0, -96.0, 352.0, 352.0], 2, False),       # sqrt(area) == 448 exactly -> level 5 (samples beyond the map are void)
+    ([-96.0, -96.0, 351.9, 351.9], 1, False),       # 447.9 -> level 4
+    ([-320.0, -320.0, 576.0, 576.0], 3, False),     # sqrt(area) == 896 exactly -> level 6
+    ([-320.0, -320.0, 575.9, 575.9], 2, False),     # 895.9 -> level 5
+    ([50.0, 50.0, 50.0, 50.0], 0, False),           # zero-area box: log2(1e-8) -> clamp to level 3; zero bins, zero samples -> all zeros
+    ([50.0, 60.0, 90.0, 60.0], 0, False),           # zero height only: no samples either
+    ([300.0, 300.0, 400.0, 400.0], 0, False),       # wholly beyond the bottom-right corner of the 256 x 256 map: every sample void
+    ([-200.0, -200.0, -100.0, -100.0], 0, False),   # wholly left / above (coordinates < -1): every sample void
+    ([16.0, 16.0, 128.0, 128.0], 0, True),          # bin size EXACTLY 2 feature pixels: ceil(2.0) = 2 samples per bin, not 3
+    ([16.0, 24.0, 184.0, 192.0], 0, True),          # bin size exactly 3: 3 x 3 samples per bin
+    ([8.0, 8.0, 64.0, 120.0], 0, True),             # 1 x 2 feature pixels per bin: non-square adaptive grid (1 x 2 samples)
+    ([250.0, 10.0, 262.0, 200.0], 0, False),        # straddles the right border: columns beyond n are void, the row range is inside
+]
+
+
+def gen_roi_align_b(out):
+    feats, params = roi_feature_pyramid()
+    boxes, levels, expect = [], [], []
+    for box, want_l, closed in ROI_CASES_B:
+        l = assign_level(box) - 3
+        assert l == want_l, (box, l, want_l)
+        s = 1.0 / (8 << l)
+        got = roi_align_matrix(feats[l], box, s)
+        if closed:
+            a, b, o = params[l]
+            x1, y1, x2, y2 = [v * s - 0.5 for v in box]
+            cx = x1 + (np.arange(7) + 0.5) * (x2 - x1) / 7
+            cy = y1 + (np.arange(7) + 0.5) * (y2 - y1) / 7
+            hand = a[:, None, None] * cx[None, None, :] + b[:, None, None] * cy[None, :, None] + o[:, None, None]
+            assert np.abs(hand - got).max() < 1e-10, (box, np.abs(hand - got).max())
+        boxes.append(box); levels.append(l); expect.append(got)
+    for k in (9, 10, 11, 12):  # degenerate / outside boxes pool to exact zeros
+        assert np.abs(expect[k]).max() == 0.0, (boxes[k], np.abs(expect[k]).max())
+    # the integral-bin cases really use ceil(bin) samples: one more sample per bin would move the (non-linear) border cases only, so
+    # pin the sample count itself on a NON-linear map: f = x^2 on level 3, box [16,16,128,128] -> bins of 2 pixels, 2 samples at
+    # bin_start + 0.5 and + 1.5: mean of the interpolated parabola differs between 2 and 3 samples per bin
+    C, Hh, Ww = 4, 32, 32
+    yy, xx = np.meshgrid(np.arange(Hh), np.arange(Ww), indexing="ij")
+    quad = np.stack([xx.astype(F64) ** 2, yy.astype(F64) ** 2, (xx * yy).astype(F64), (xx + 2.0 * yy).astype(F64)])
+    qbox = [16.0, 16.0, 128.0, 128.0]
+    qgot = roi_align_matrix(quad, qbox, 1.0 / 8)
+    # hand: bin p covers feature x in [1.5 + 2p, 3.5 + 2p); samples at 2 + 2p and 3 + 2p (ON pixel centres): mean of x^2 = ((2+2p)^2 + (3+2p)^2) / 2
+    px = np.arange(7)
+    hand_x2 = ((2.0 + 2 * px) ** 2 + (3.0 + 2 * px) ** 2) / 2.0
+    assert np.abs(qgot[0] - hand_x2[None, :]).max() < 1e-9
+    assert np.abs(qgot[1] - hand_x2[:, None]).max() < 1e-9
+    out["roi_boxes"] = np.asarray(boxes, np.float32)
+    out["roi_levels"] = np.asarray(levels, np.int64)
+    out["roi_expect"] = np.asarray(expect).astype(np.float32)
+    out["quad_feat"] = quad.astype(np.float32)
+    out["quad_box"] = np.asarray([qbox], np.float32)
+    out["quad_expect"] = qgot.astype(np.float32)
+    print("roi_align (b):", len(boxes), "cases, levels", levels)
+
+
+def gen_nms_b(out):
+    """Image 0 (128 x 128): 70 disjoint class-0 boxes (two 64-box chunks of the sorted pool) + candidates that must be suppressed
+    ACROSS the chunk boundary / inside the second chunk / kept because of their class.  Image 1 (64 x 64 in a 128 x 128 pad): IoU
+    == 0.6 exactly with the score order reversed, score ties in both geometric orders, clipping at 0, non-square rescale to empty."""
+    shapes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    N, B = 3, 2
+    logits = [np.full((B, N, h, w), -20.0, F64) for h, w in shapes]
+    reg = [np.zeros((B, 4, h, w), F64) for h, w in shapes]
+    ctr = [np.full((B, 1, h, w), 20.0, F64) for h, w in shapes]
+    loc_base = np.cumsum([0] + [h * w for h, w in shapes])
+
+    def put(b, lvl, i, j, cls, logit, box):
+        st = 8 << lvl
+        x, y = st * j + st // 2, st * i + st // 2
+        l, t, r, bt = (x - box[0]) / st, (y - box[1]) / st, (box[2] - x) / st, (box[3] - y) / st
+        assert min(l, t, r, bt) >= 0, (box, x, y)
+        assert logits[lvl][b, cls, i, j] == -20.0
+        logits[lvl][b, cls, i, j] = logit
+        reg[lvl][b, :, i, j] = (l, t, r, bt)
+        return {"b": b, "ord": int(loc_base[lvl] + i * shapes[lvl][1] + j) * N + cls, "cls": cls,
+                "score": math.sqrt(sigmoid(logit) * sigmoid(20.0)), "box": list(map(float, box)), "xy": (float(x), float(y)), "lvl": lvl}
+
+    def iou(a, b):
+        iw = max(min(a[2], b[2]) - max(a[0], b[0]), 0.0); ih = max(min(a[3], b[3]) - max(a[1], b[1]), 0.0)
+        inter = iw * ih
+        return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+    def brute_nms(cands, thr=0.6):
+        order = sorted(range(len(cands)), key=lambda k: (-cands[k]["score"], cands[k]["ord"]))
+        dead, keep = set(), []
+        for a_i, ia in enumerate(order):
+            if ia in dead:
+                continue
+            keep.append(ia)
+            for ib in order[a_i + 1:]:
+                if ib not in dead and cands[ia]["cls"] == cands[ib]["cls"] and iou(cands[ia]["box"], cands[ib]["box"]) > thr:
+                    dead.add(ib)
+        return [cands[k] for k in keep], order
+
+    # ---- image 0
+    grid = []
+    for k in range(70):
+        i, j = k // 16, k % 16
+        grid.append(put(0, 0, i, j, 0, 3.0 - 0.02 * k, [8 * j, 8 * i, 8 * j + 8, 8 * i + 8]))
+    # level-1 locations (16 j + 8, 16 i + 8) are corners of level-0 cells: a box ending at the location overlaps the cell up-left of it
+    X = put(0, 1, 0, 0, 0, -1.0, [0.5, 0.5, 8, 8])        # vs grid[0] = [0,0,8,8] (rank 0, chunk 0): IoU 56.25/64 = 0.879 -> suppressed; X ranks 70+ (chunk 1)
+    Y = put(0, 1, 2, 1, 0, -1.1, [16.5, 32.5, 24, 40])    # vs grid[66] = cell (i=4, j=2) = [16,32,24,40] (rank 66, chunk 1): suppressed inside chunk 1
+    Z = put(0, 1, 0, 1, 1, -1.2, [16.5, 0.5, 24, 8])      # overlaps grid[2] = [16,0,24,8] but is class 1: kept
+    V = put(0, 1, 0, 2, 0, -1.3, [35.2, 0, 40, 8])        # vs grid[4] = [32,0,40,8]: IoU = 38.4/64 = 0.6 (binary-rounded just BELOW 0.6 in fp32 and fp64): kept
+    assert abs(iou(X["box"], grid[0]["box"]) - 0.87890625) < 1e-12 and iou(Y["box"], grid[66]["box"]) > 0.6
+    assert iou(V["box"], grid[4]["box"]) <= 0.6 and np.float32(38.4) / np.float32(64.0) <= np.float32(0.6)
+    img0 = grid + [X, Y, Z, V]
+    keep0, order0 = brute_nms(img0)
+    assert [id(c) for c in keep0] == [id(c) for c in grid + [Z, V]]
+    assert order0.index(70) >= 64 and order0.index(71) >= 64 and order0.index(66) >= 64 and order0.index(0) < 64  # the chunk layout the case is about
+
+    # ---- image 1: valid image 64 x 64 (inside the 128 x 128 pad), output 96 (h) x 80 (w): sy = 1.5, sx = 1.25
+    A = put(1, 0, 0, 0, 0, 1.0, [0, 0, 40, 40])
+    Bh = put(1, 0, 0, 1, 0, 2.0, [0, 0, 40, 24])          # IoU(A, Bh) = 0.6 exactly, Bh scores HIGHER: Bh first, A survives (not > 0.6)
+    Ch = put(1, 0, 1, 0, 0, 2.5, [0, 0, 40, 25])          # IoU(A, Ch) = 0.625, Ch higher: A is suppressed by Ch after all; IoU(Bh, Ch) = 0.96: Bh suppressed too
+    T1 = put(1, 0, 6, 6, 2, 0.0, [44, 44, 60, 60])        # score tie, lower ordinal, the LARGER box
+    T2 = put(1, 0, 6, 7, 2, 0.0, [46, 44, 60, 60])        # IoU = 224/256 = 0.875: suppressed by T1 (lower ordinal wins)
+    U1 = put(1, 0, 3, 6, 1, 0.0, [46, 20, 60, 36])        # the same tie with the geometry swapped: lower ordinal has the SMALLER box
+    U2 = put(1, 0, 3, 7, 1, 0.0, [44, 20, 60, 36])        # suppressed by U1
+    Ng = put(1, 0, 0, 4, 1, 1.5, [-12, -20, 44, 12])      # clipped at 0: -> [0, 0, 44, 12] * (1.25, 1.5) = [0, 0, 55, 18]
+    Em = put(1, 0, 7, 0, 2, 0.7, [0, 58, 6, 70])          # beyond the bottom: y0 * 1.5 = 87, y1 -> clip 96; kept: [0, 87, 7.5, 96]
+    Eh = put(1, 0, 8, 3, 0, 0.6, [20, 64, 30, 72])        # y0 * 1.5 = 96 = the output height: clipped to an EMPTY box -> dropped
+    img1 = [A, Bh, Ch, T1, T2, U1, U2, Ng, Em, Eh]
+    keep1_all, _ = brute_nms(img1)
+    assert [id(c) for c in keep1_all] == [id(c) for c in [Ch, Ng, Em, Eh, U1, T1]], [img1.index(c) for c in keep1_all]
+    sx, sy, ow, oh = 80 / 64.0, 96 / 64.0, 80.0, 96.0
+    post1, keep1 = [], []
+    for c in keep1_all:
+        x0, y0, x1, y1 = c["box"]
+        bx = [min(max(x0 * sx, 0.0), ow), min(max(y0 * sy, 0.0), oh), min(max(x1 * sx, 0.0), ow), min(max(y1 * sy, 0.0), oh)]
+        if bx[2] - bx[0] > 0 and bx[3] - bx[1] > 0:  # Boxes.nonempty()
+            keep1.append(c); post1.append(bx)
+    assert [id(c) for c in keep1] == [id(c) for c in [Ch, Ng, Em, U1, T1]]
+    assert post1[1] == [0.0, 0.0, 55.0, 18.0] and post1[2] == [0.0, 87.0, 7.5, 96.0]
+
+    for l in range(5):
+        out[f"nms_logits{l}"] = logits[l].astype(np.float32)
+        out[f"nms_reg{l}"] = reg[l].astype(np.float32)
+        out[f"nms_ctr{l}"] = ctr[l].astype(np.float32)
+    out["nms_image_sizes"] = np.array([[128, 128], [64, 64]])
+    out["nms_out_sizes"] = np.array([[128, 128], [96, 80]])
+    for i, (keep, boxes) in enumerate(((keep0, [c["box"] for c in keep0]), (keep1, post1))):
+        out[f"nms_img{i}_boxes"] = np.asarray(boxes, np.float32)
+        out[f"nms_img{i}_scores"] = np.asarray([c["score"] for c in keep], np.float32)
+        out[f"nms_img{i}_classes"] = np.asarray([c["cls"] for c in keep], np.int64)
+        out[f"nms_img{i}_locations"] = np.asarray([c["xy"] for c in keep], np.float32)
+        out[f"nms_img{i}_cand"] = np.asarray([c["ord"] for c in keep], np.int64)
+    print("nms/postprocess (b): image 0 keeps", len(keep0), "of", len(img0), "; image 1 keeps", len(keep1), "of", len(img1))
+
+
+def write_b():
+    out = {}
+    gen_roi_align_b(out)
+    gen_nms_b(out)
+    np.savez_compressed(os.path.join(HERE, "g8b_known_answers.npz"), **out)
+    print("wrote g8b_known_answers.npz", os.path.getsize(os.path.join(HERE, "g8b_known_answers.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     out = {}
-    gen_roi_align(out)
-    gen_nms_postprocess(out)
-    gen_backbone(out)
-    np.savez_compressed(os.path.join(HERE, "g8_known_answers.npz"), **out)
-    print("wrote g8_known_answers.npz", os.path.getsize(os.path.join(HERE, "g8_known_answers.npz")) // 1024, "KiB")
+    if "--only-b" not in sys.argv:
+        gen_roi_align(out)
+        gen_nms_postprocess(out)
+        gen_backbone(out)
+    if "--only-b" not in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "g8_known_answers.npz"), **out)
+        print("wrote g8_known_answers.npz", os.path.getsize(os.path.join(HERE, "g8_known_answers.npz")) // 1024, "KiB")
+    write_b()

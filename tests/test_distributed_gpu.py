@@ -128,6 +128,50 @@ def test_rccl_backend_world1_gather_reduce():
     assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+_CABI_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, "%(root)s/sylph-few-shot-detection_amd")
+from sylph_amd import distributed as D
+from sylph_amd.engine import Engine
+eng = Engine(None, dtype="f32")
+gat = D.CAbiCodeGather(eng, rank=0, world=1)           # sylph_comm_unique_id + sylph_comm_init_rank: no torch.distributed at all
+g = torch.Generator().manual_seed(4)
+conv, bias = torch.randn(5, 256, generator=g).cuda(), torch.randn(5, generator=g).cuda()
+local = D.pack_codes(conv, bias, [4, 0, 2, 4, 1], acc_weight=[0.5, 1.0, 1.0, 0.25, 1.0], names=["e", "a", "c", "e", "b"])
+rows = gat.gather(local, 8)                              # sylph_allgather_codes: ONE in-place ncclAllGather on the engine's stream
+torch.cuda.synchronize()
+assert rows.shape == (8, D.ROW) and torch.equal(rows[:5], local) and float(rows[5:].abs().sum()) == 0.0
+full = gat.gather(local, 5)                              # n_local == capacity: no padding memset
+torch.cuda.synchronize()
+assert torch.equal(full, local)
+D.install_c_abi_gather(gat)                              # ... and as the transport of the reference-shaped API
+rows2 = D.gather_packed_codes(local, capacity=8)
+torch.cuda.synchronize()
+assert torch.equal(rows2, rows)
+D.install_c_abi_gather(None)
+try:
+    gat.gather(local, 3)
+    raise SystemExit("an over-full block must be refused")
+except RuntimeError as e:
+    assert "do not fit" in str(e), e
+red = eng.reduce_codes(rows.contiguous(), 5).cpu()
+assert D.unpack_names(red) == ["a", "b", "c", "", "e"]
+gat.close()
+print("CABI_GATHER_OK")
+"""
+
+
+def test_c_abi_allgather_codes_world1():
+    """the episode's one collective is reachable WITHOUT torch: sylph_comm_unique_id / sylph_comm_init_rank /
+    sylph_allgather_codes (RCCL resolved with dlopen inside libsylph_hip.so).  World 1 on the one GPU of the test box: the id
+    hand-off, the communicator, the in-place ncclAllGather, padding and the capacity check are exercised; the N > 1 behaviour is
+    ncclAllGather's own."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _CABI_SCRIPT % {"root": ROOT}], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "CABI_GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def _run_bench(nranks, tmp_path, tag, extra=()):
     """bench.py under torch.distributed.run with `nranks` ranks sharing the ONE GPU of the test box over gloo
     (SYLPH_BENCH_BACKEND=gloo SYLPH_BENCH_ONE_DEVICE=1): the multi-rank control flow of the script -- class / query shards incl.

@@ -49,6 +49,55 @@ def test_nms_and_postprocess_known_answers(g8):
         np.testing.assert_allclose(r["pred_boxes"].numpy(), g8[f"nms_img{i}_boxes"], atol=1e-5)
 
 
+# ---- round 4: g8b (level boundaries incl. the 1e-8 epsilon, degenerate / outside boxes, integral adaptive bins, a non-linear map
+# that pins the SAMPLE COUNT; NMS over two 64-box chunks, IoU == 0.6 with the score order reversed, ties in both geometric orders,
+# clipping at 0 and to empty under a non-square rescale) ------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def g8b(golden_dir):
+    return np.load(os.path.join(golden_dir, "g8b_known_answers.npz"))
+
+
+def test_level_assignment_boundaries(g8b):
+    lv = OR.assign_boxes_to_levels(torch.from_numpy(g8b["roi_boxes"]))
+    np.testing.assert_array_equal(lv.numpy(), g8b["roi_levels"])
+
+
+def test_roi_align_degenerate_outside_and_integral_bins(g8, g8b):
+    S = g8b["roi_boxes"].shape[0]
+    feats = [torch.from_numpy(g8[f"roi_feat{l}"])[None].repeat(S, 1, 1, 1) for l in range(5)]
+    got = OR.roi_pooler(feats, torch.from_numpy(g8b["roi_boxes"])).numpy()
+    np.testing.assert_allclose(got, g8b["roi_expect"], atol=2e-5, rtol=2e-6)
+    for k in (9, 10, 11, 12):  # zero-area, zero-height, wholly outside (both sides): exact zeros, not NaN
+        assert np.all(got[k] == 0.0), k
+
+
+def test_roi_align_sample_count_on_a_parabola(g8b):
+    """bin size exactly 2 feature pixels -> ceil(2.0) = 2 samples per bin and direction; on f = x^2 three samples would give another mean."""
+    q = torch.from_numpy(g8b["quad_feat"])[None]
+    feats = [torch.nn.functional.pad(q, (0, 0, 0, 0, 0, 252))] + [torch.zeros(1, 256, 32 >> l, 32 >> l) for l in range(1, 5)]
+    got = OR.roi_pooler(feats, torch.from_numpy(g8b["quad_box"])).numpy()[0, :4]
+    np.testing.assert_allclose(got, g8b["quad_expect"], atol=1e-4, rtol=1e-6)
+
+
+def test_nms_two_chunks_reversed_ties_and_clipping(g8b):
+    logits = [torch.from_numpy(g8b[f"nms_logits{l}"]) for l in range(5)]
+    regs = [torch.from_numpy(g8b[f"nms_reg{l}"]) for l in range(5)]
+    ctrs = [torch.from_numpy(g8b[f"nms_ctr{l}"]) for l in range(5)]
+    ious = [torch.zeros_like(c) for c in ctrs]
+    props = OD.predict_proposals(logits, regs, ctrs, ious)
+    loc_base = np.cumsum([0, 256, 64, 16, 4])
+    for i, p in enumerate(props):
+        img, osz = tuple(g8b["nms_image_sizes"][i]), tuple(g8b["nms_out_sizes"][i])
+        r = OD.detector_postprocess(p, img, int(osz[0]), int(osz[1]))
+        np.testing.assert_array_equal(r["pred_classes"].numpy(), g8b[f"nms_img{i}_classes"])
+        np.testing.assert_array_equal(r["locations"].numpy(), g8b[f"nms_img{i}_locations"])
+        np.testing.assert_allclose(r["scores"].numpy(), g8b[f"nms_img{i}_scores"], atol=1e-6)
+        np.testing.assert_allclose(r["pred_boxes"].numpy(), g8b[f"nms_img{i}_boxes"], atol=1e-5)
+    p0 = props[0]  # the keep list itself, as global candidate ordinals (level offset + location) * N + class
+    ords = (torch.from_numpy(loc_base)[p0["fpn_levels"]] + p0["loc_index"]) * 3 + p0["pred_classes"]
+    np.testing.assert_array_equal(ords.numpy(), g8b["nms_img0_cand"])
+
+
 @pytest.fixture(scope="module")
 def bb_sd(g8):
     sd = W.backbone_state_dict(0, depth=50)

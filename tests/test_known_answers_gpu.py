@@ -68,6 +68,58 @@ def test_nms_and_postprocess_known_answers(g8):
         np.testing.assert_allclose(d["pred_boxes"].cpu().numpy(), g8[f"nms_img{i}_boxes"], atol=1e-5)
 
 
+@pytest.fixture(scope="module")
+def g8b(golden_dir):
+    return np.load(os.path.join(golden_dir, "g8b_known_answers.npz"))
+
+
+def test_roi_align_boundaries_degenerate_and_integral_bins(g8, g8b):
+    """g8b ROI cases through roi_align_kernel: sqrt(area) exactly 112 / 224 / 448 / 896 and just below (the 1e-8 epsilon of
+    assign_boxes_to_levels decides the exact ones), zero-area and zero-height boxes, boxes wholly outside the map on either side
+    (exact zeros), bins of exactly 2 / 3 feature pixels, a box straddling the right border."""
+    from sylph_amd import synthetic as W
+    eng = _engine()
+    eng.load_state_dict(W.codegen_state_dict(seed=2))
+    S = g8b["roi_boxes"].shape[0]
+    feats = [torch.from_numpy(g8[f"roi_feat{l}"])[None].repeat(S, 1, 1, 1) for l in range(5)]
+    eng.import_pyramid(feats, (256, 256))
+    got = eng.roi_align(torch.from_numpy(g8b["roi_boxes"])).cpu().numpy()
+    np.testing.assert_allclose(got, g8b["roi_expect"], atol=5e-5, rtol=1e-5)
+    for k in (9, 10, 11, 12):
+        assert np.all(got[k] == 0.0), k
+    # the sample count itself, on a parabola (see gen_known_answers.py)
+    q = torch.from_numpy(g8b["quad_feat"])[None]
+    feats = [torch.nn.functional.pad(q, (0, 0, 0, 0, 0, 252))] + [torch.zeros(1, 256, 32 >> l, 32 >> l) for l in range(1, 5)]
+    eng.import_pyramid(feats, (256, 256))
+    got = eng.roi_align(torch.from_numpy(g8b["quad_box"])).cpu().numpy()[0, :4]
+    np.testing.assert_allclose(got, g8b["quad_expect"], atol=1e-4, rtol=1e-6)
+
+
+def test_nms_two_chunks_reversed_ties_and_clipping(g8b):
+    """g8b decode cases through decode + nms_kernel: 70 kept boxes of one class (the walk crosses the 64-box chunk boundary), a
+    candidate of the second chunk suppressed by a box kept in the FIRST, one suppressed inside the second chunk, one kept for its
+    class, IoU == 0.6 (not suppressed) incl. the reversed score order, score ties in both geometric orders (lower ordinal wins),
+    clipping at 0 and to an empty box under a 1.25 x 1.5 rescale."""
+    from sylph_amd import synthetic as W
+    eng = _engine()
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60))
+    sizes = [tuple(int(v) for v in s) for s in g8b["nms_image_sizes"]]
+    outs = [tuple(int(v) for v in s) for s in g8b["nms_out_sizes"]]
+    shapes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    eng.import_pyramid([torch.zeros(2, 256, h, w) for h, w in shapes], (128, 128), sizes)
+    eng.import_head([torch.from_numpy(g8b[f"nms_logits{l}"]) for l in range(5)],
+                    [torch.from_numpy(g8b[f"nms_reg{l}"]) for l in range(5)],
+                    [torch.from_numpy(g8b[f"nms_ctr{l}"]) for l in range(5)],
+                    [torch.zeros(2, 1, h, w) for h, w in shapes])
+    dets = eng.decode(outs)
+    np.testing.assert_array_equal(dets[0]["cand_index"].cpu().numpy(), g8b["nms_img0_cand"])
+    for i, d in enumerate(dets):
+        np.testing.assert_array_equal(d["pred_classes"].cpu().numpy(), g8b[f"nms_img{i}_classes"])
+        np.testing.assert_array_equal(d["locations"].cpu().numpy(), g8b[f"nms_img{i}_locations"])
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), g8b[f"nms_img{i}_scores"], atol=1e-6)
+        np.testing.assert_allclose(d["pred_boxes"].cpu().numpy(), g8b[f"nms_img{i}_boxes"], atol=1e-5)
+
+
 def _bn(sd, p):
     from oracle import backbone as OB  # scale/shift folding only (host constants for sylph_conv2d)
     return OB.bn_scale_shift(sd, p)
