@@ -237,16 +237,6 @@ int sylph_bottleneck(sylph_ctx* ctx, const float* x_nchw_dev, int B, int Cin, in
                      const float* const* w_host, const float* const* scale_host, const float* const* shift_host,
                      float* y_nchw_dev);
 
-/* Kernel parity entry: TWO consecutive identity BottleneckBlocks (Cin == cout == C, stride 1) through the launches
- * sylph_backbone_fpn uses for such a pair -- with C = 4 * mid, mid in {128, 256} (res3 / res4 shapes), bf16 and enough rows (or
- * SYLPH_FUSE_DUAL=2) that is conv1, conv2, ONE dual-output launch (conv3 + residual + ReLU of block 0 and conv1 + ReLU of block 1,
- * conv_dual.hip), conv2, conv3.  w_host[6] / scale_host[6] / shift_host[6]: conv1, conv2, conv3 of block 0, then of block 1.
- * y_mid (may be NULL): block 0's output, y: block 1's output, both (B,C,H,W) fp32 NCHW device.
- * (call site meta_one_stage_detector.py:181,273) */
-int sylph_bottleneck_pair(sylph_ctx* ctx, const float* x_nchw_dev, int B, int C, int H, int W, int mid,
-                          const float* const* w_host, const float* const* scale_host, const float* const* shift_host,
-                          float* y_mid_nchw_dev, float* y_nchw_dev);
-
 /* Kernel parity entry: one FPN lateral as sylph_backbone_fpn launches it (detectron2 FPN.forward: lateral 1x1 conv + bias, plus
  * the nearest-2x upsampled level above, fused as a residual; call site meta_one_stage_detector.py:181,273).  x (B,C,H,W) fp32 NCHW
  * device; w_host (256,C,1,1), bias_host (256); top (B,256,H/2,W/2) device or NULL (fpn_lateral5); y (B,256,H,W) fp32 NCHW device. */

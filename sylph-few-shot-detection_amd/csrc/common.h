@@ -74,24 +74,6 @@ struct ConvArgs {
 // conv_pw.hip tile descriptor (two s_load_dwordx8): geometry of the tile's segment + the tile's first row
 struct PwDesc { int row0, seg_rows, out_W, out_row0, in_row0, in_W, in2_row0, in2_W, res_row0, res_W, pad[6]; };
 
-// conv_dual.hip: conv3 (+ residual + ReLU) of one identity bottleneck and conv1 (+ ReLU) of the next in one pass over the rows
-struct DualArgs {
-  const void* in;      // t2 [rows][mid] bf16
-  const void* w3;      // conv3 stage images (launch_dual_pack)
-  const float* tab3;   // [C / 128][scale 128 | shift 128] fp32 (launch_pw_pack_table, BN = 128)
-  const void* res;     // x [rows][C] bf16: the residual
-  void* out;           // y [rows][C] bf16
-  const void* w1;      // the next block's conv1 stage images in the register-operand k order (launch_dual_pack)
-  const float* tab1;   // [scale mid | shift mid] fp32
-  void* out2;          // t1' [rows][mid] bf16
-  void* trash;         // >= 4 KiB: where lanes without a valid output row put their (fixed number of) stores
-  const PwDesc* desc;  // one descriptor per 128-row tile (row0, seg_rows, out_row0, in_row0, res_row0 are used)
-  int n_mtiles;
-  int C;               // channels of x / y
-  int in_ld, res_ld, out_ld, out2_ld;  // row strides in elements
-  int ablate;          // -DSYLPH_ABLATE builds only (SYLPH_DUAL_ABLATE): 1 no residual loads, 2 no y stores, 4 no GEMM-2 MFMAs, 8 no GEMM-1 MFMAs, 16 no t1' stores
-};
-
 // fused identity bottleneck (bottleneck.hip): x, y [pos][256] bf16; w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16
 // (the conv_igemm weight layouts); FrozenBN scale / shift per conv (fp32)
 struct BkTile { int row0, H, W, yx, ph, pw; unsigned inv_pw, inv_hw2; };  // one 32-byte descriptor per patch (s_load_dwordx8)
@@ -171,9 +153,5 @@ bool conv_pw_ok(DType dt, bool out_f32, const ConvArgs& a);
 int launch_conv_pw(const ConvArgs& a, int BM, int BN, hipStream_t s);
 int launch_pw_pack_weights(const void* w_igemm, void* w_pw, int Cout, int K, int BN, hipStream_t s);
 int launch_pw_pack_table(const float* scale, const float* shift, float* out, int Cout, int BN, hipStream_t s);
-// conv_dual.hip: mid = 128 (res3) or 256 (res4)
-bool conv_dual_ok(const DualArgs& a, int mid);
-int launch_conv_dual(const DualArgs& a, int mid, hipStream_t s);
-int launch_dual_pack(const void* w3_igemm, const void* w1_igemm, void* w3_out, void* w1_out, int C, int mid, hipStream_t s);
 
 }  // namespace sylph

@@ -171,8 +171,6 @@ struct sylph_ctx {
   std::map<const void*, void*> hp_weights;  // conv_hpipe.hip re-packed copies of 3x3 weights, keyed by the igemm-layout pointer
   std::map<const void*, std::pair<void*, float*>> pw_weights;  // conv_pw.hip stage-image copies of 1x1 weights + scale/shift tables, keyed by the igemm-layout pointer
   void* pw_trash = nullptr;                 // conv_pw.hip trash slots (4 KiB)
-  struct DualW { void *w3 = nullptr, *w1 = nullptr; float *tab3 = nullptr, *tab1 = nullptr; };
-  std::map<std::pair<const void*, const void*>, DualW> dual_weights;  // conv_dual.hip stage images, keyed by (conv3, next conv1) igemm-layout pointers
   Plan* cur = nullptr;
   void* zeros = nullptr;  // 256 B of zeros (conv out-of-image taps)
   // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
@@ -882,22 +880,8 @@ static int ensure_pyramid(sylph_ctx* c, Plan* P) {
 // appended to `ops`: X [B][Hin*Win][Cin] -> Y [B][Ho*Wo][cout].  t1 / t2 / sc are scratch activations of the stage.
 // Shared by build_backbone and the single-block parity entry sylph_bottleneck, so both run the same kernels.
 struct BkScratch { void *t1, *t2, *sc; void** trash; };
-// Can conv3 of identity block `blk` and conv1 of the identity block `next` behind it run as ONE dual-output launch (conv_dual.hip)?
-static bool dual_eligible(sylph_ctx* c, const sylph_ctx::Block& blk, const sylph_ctx::Block* next, int B, int H, int W, int mid, int cout) {
-  static const int on = getenv("SYLPH_FUSE_DUAL") ? atoi(getenv("SYLPH_FUSE_DUAL")) : 1;
-  if (!on || !next || c->dt != DT_BF16 || blk.has_sc || next->has_sc || (mid != 128 && mid != 256) || cout != 4 * mid) return false;
-  if (blk.c3.Cout_pad != cout || blk.c3.Cin != mid || next->c1.Cin != cout || next->c1.Cout_pad != mid || next->c1.Cout != mid) return false;
-  const long rows = (long)B * H * W, tiles = (long)B * ((H * W + 127) / 128);
-  // 32-bit byte offsets into x / y; at least two row tiles per block slot, else the per-layer launches fill the chip better
-  return rows * cout * 2 < (1L << 32) && (on == 2 || tiles >= 1024);
-}
-
-// t1_ready: this block's conv1 output is already in scr.t1 (written by the previous block's dual launch).  next / *fused_next: the
-// block behind this one; set when its conv1 was computed here (conv3 + residual + next conv1 as one conv_dual launch).
 static int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block& blk, int B, const void* X, int Cin, int Hin, int Win,
-                          int stride, int mid, int cout, void* Y, const BkScratch& scr, bool t1_ready = false,
-                          const sylph_ctx::Block* next = nullptr, bool* fused_next = nullptr) {
-  if (fused_next) *fused_next = false;
+                          int stride, int mid, int cout, void* Y, const BkScratch& scr) {
   const DType dt = c->dt;
   const int s1 = c->cfg.stride_in_1x1 ? stride : 1, s3 = c->cfg.stride_in_1x1 ? 1 : stride;
   const int H1 = (Hin - 1) / s1 + 1, W1 = (Win - 1) / s1 + 1;
@@ -945,58 +929,10 @@ static int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx:
     else ops.push_back([=](hipStream_t s) { return timed_op(c, "bottleneck64p_kernel", fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
     return 0;
   }
-  if (!t1_ready) {
-    ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
-    RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
-  }
+  ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
+  RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
   ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
   RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
-  if (stride == 1 && Cin == cout && dual_eligible(c, blk, next, B, Ho, Wo, mid, cout)) {
-    // conv3 + residual + ReLU of this block and conv1 + ReLU of the next one: the y rows go from the accumulators of the first GEMM
-    // into the second as register operands (conv_dual.hip); t1 (dead since conv2 above) receives the next block's conv1 output
-    auto key = std::make_pair((const void*)blk.c3.w, (const void*)next->c1.w);
-    auto it = c->dual_weights.find(key);
-    if (it == c->dual_weights.end()) {
-      sylph_ctx::DualW dw;
-      OwnerScope ctx_owned(c, nullptr);  // re-packed weights outlive the plan that first needed them
-      RET(c->dalloc(&dw.w3, (size_t)cout * mid * 2));
-      RET(c->dalloc(&dw.w1, (size_t)cout * mid * 2));
-      RET(c->dalloc((void**)&dw.tab3, (size_t)2 * cout * sizeof(float)));
-      RET(c->dalloc((void**)&dw.tab1, (size_t)2 * mid * sizeof(float)));
-      KCHK(launch_dual_pack(blk.c3.w, next->c1.w, dw.w3, dw.w1, cout, mid, c->stream), "dual_pack");
-      KCHK(launch_pw_pack_table(blk.c3.scale, blk.c3.shift, dw.tab3, cout, 128, c->stream), "dual_table3");
-      KCHK(launch_pw_pack_table(next->c1.scale, next->c1.shift, dw.tab1, mid, mid, c->stream), "dual_table1");
-      HIPCHK(hipStreamSynchronize(c->stream));
-      it = c->dual_weights.emplace(key, dw).first;
-    }
-    if (!c->pw_trash) {
-      OwnerScope ctx_owned(c, nullptr);
-      RET(c->dalloc(&c->pw_trash, 8192));
-    }
-    std::vector<PwDesc> pd;
-    const int nrows = Ho * Wo;
-    for (int b = 0; b < B; ++b)
-      for (int r = 0; r < nrows; r += 128) {
-        PwDesc d;
-        memset(&d, 0, sizeof(d));
-        d.row0 = r; d.seg_rows = nrows; d.out_W = Wo; d.out_row0 = b * nrows; d.in_row0 = b * nrows; d.in_W = Wo;
-        d.in2_row0 = 0; d.in2_W = Wo; d.res_row0 = b * nrows; d.res_W = Wo;
-        pd.push_back(d);
-      }
-    void* pdd = nullptr;
-    RET(upload(c, &pdd, pd.data(), pd.size() * sizeof(PwDesc)));
-    DualArgs da;
-    memset(&da, 0, sizeof(da));
-    da.in = t2; da.w3 = it->second.w3; da.tab3 = it->second.tab3; da.res = X; da.out = Y;
-    da.w1 = it->second.w1; da.tab1 = it->second.tab1; da.out2 = t1; da.trash = c->pw_trash;
-    da.desc = (const PwDesc*)pdd; da.n_mtiles = (int)pd.size(); da.C = cout;
-    da.in_ld = mid; da.res_ld = Cin; da.out_ld = cout; da.out2_ld = mid;
-    if (!conv_dual_ok(da, mid)) return fail("internal: conv_dual selected for a block pair it cannot run");
-    const double fl = 2.0 * (double)B * nrows * ((double)mid * cout + (double)cout * mid);
-    ops.push_back([=](hipStream_t s) { return timed_op(c, mid == 128 ? "conv_dual_kernel<128>" : "conv_dual_kernel<256>", fl, s, [=](hipStream_t st) { return launch_conv_dual(da, mid, st); }); });
-    if (fused_next) *fused_next = true;
-    return 0;
-  }
   if (blk.fused_sc) {
     // conv3 + projection shortcut as ONE pointwise GEMM over K = [t2 | X(strided)]: the shortcut
     // tensor is never written to / re-read from HBM
@@ -1084,14 +1020,10 @@ static int build_backbone(sylph_ctx* c, Plan* P) {
     auto& blocks = c->stages[si];
     void* Y = nullptr;
     BkScratch scr{t1, t2, sc, &P->bk_trash};
-    bool t1_ready = false;
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
       const int stride = bi == 0 ? first_stride : 1;
       Y = (Y == Ya) ? Yb : Ya;
-      bool fused_next = false;
-      RET(add_bottleneck(c, ops, blocks[bi], B, X, Cin, Hin, Win, stride, mid, cout, Y, scr, t1_ready,
-                         bi + 1 < blocks.size() ? &blocks[bi + 1] : nullptr, &fused_next));
-      t1_ready = fused_next;
+      RET(add_bottleneck(c, ops, blocks[bi], B, X, Cin, Hin, Win, stride, mid, cout, Y, scr));
       X = Y; Hin = (Hin - 1) / stride + 1; Win = (Win - 1) / stride + 1; Cin = cout;
     }
     stage_out[si] = X; stage_h[si] = Hin; stage_w[si] = Win;
@@ -2470,50 +2402,6 @@ int sylph_bottleneck(sylph_ctx* c, const float* x, int B, int Cin, int H, int W,
   for (int b = 0; b < B; ++b)
     KCHK(launch_export_nchw(c->dt, yout, y + (size_t)b * cout * Ho * Wo, cout, Ho * Wo, b * Ho * Wo, cout, c->stream), "export");
   return 0;
-}
-
-int sylph_bottleneck_pair(sylph_ctx* c, const float* x, int B, int C, int H, int W, int mid, const float* const* w_host,
-                          const float* const* scale_host, const float* const* shift_host, float* y_mid, float* y) {
-  HIPCHK(hipSetDevice(c->device));
-  const int bk = c->dt == DT_BF16 ? 64 : 32;
-  if (C % bk != 0 || mid % bk != 0) return fail("sylph_bottleneck_pair: channel counts must be multiples of " + std::to_string(bk));
-  sylph_ctx tmp;  // scratch allocations freed on return
-  tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros; tmp.cfg = c->cfg;
-  struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
-  sylph_ctx::Block blk[2];
-  const int cins[3] = {C, mid, mid}, couts[3] = {mid, mid, C}, ks[3] = {1, 3, 1};
-  HostTensor hw[6];
-  for (int b = 0; b < 2; ++b) {
-    ConvLayer* Ls[3] = {&blk[b].c1, &blk[b].c2, &blk[b].c3};
-    for (int i = 0; i < 3; ++i) {
-      const int k = b * 3 + i;
-      hw[k].shape = {couts[i], cins[i], ks[i], ks[i]};
-      hw[k].data.assign(w_host[k], w_host[k] + (size_t)couts[i] * cins[i] * ks[i] * ks[i]);
-      RET(pack_conv(&tmp, {&hw[k]}, Ls[i]));
-      RET(upload_vec(&tmp, &Ls[i]->scale, std::vector<float>(scale_host[k], scale_host[k] + couts[i]), Ls[i]->Cout_pad));
-      RET(upload_vec(&tmp, &Ls[i]->shift, std::vector<float>(shift_host[k], shift_host[k] + couts[i]), Ls[i]->Cout_pad));
-    }
-  }
-  const size_t e = tmp.esz();
-  void *xin, *ya, *yb, *t1, *t2, *sc = nullptr, *trash = nullptr;
-  RET(tmp.dalloc(&xin, (size_t)B * H * W * C * e));
-  RET(tmp.dalloc(&ya, (size_t)B * H * W * C * e));
-  RET(tmp.dalloc(&yb, (size_t)B * H * W * C * e));
-  RET(tmp.dalloc(&t1, (size_t)B * H * W * mid * e));
-  RET(tmp.dalloc(&t2, (size_t)B * H * W * mid * e));
-  for (int b = 0; b < B; ++b)
-    KCHK(launch_import_nchw(c->dt, x + (size_t)b * C * H * W, xin, C, H * W, b * H * W, C, c->stream), "import");
-  std::vector<OpFn> ops;
-  BkScratch scr{t1, t2, sc, &trash};
-  bool fused = false;
-  RET(add_bottleneck(&tmp, ops, blk[0], B, xin, C, H, W, 1, mid, C, ya, scr, false, &blk[1], &fused));
-  RET(add_bottleneck(&tmp, ops, blk[1], B, ya, C, H, W, 1, mid, C, yb, scr, fused, nullptr, nullptr));
-  RET(run_ops(c, ops, "bottleneck_pair"));
-  for (int b = 0; b < B; ++b) {
-    if (y_mid) KCHK(launch_export_nchw(c->dt, ya, y_mid + (size_t)b * C * H * W, C, H * W, b * H * W, C, c->stream), "export");
-    KCHK(launch_export_nchw(c->dt, yb, y + (size_t)b * C * H * W, C, H * W, b * H * W, C, c->stream), "export");
-  }
-  return fused ? 0 : 0;
 }
 
 int sylph_fpn_lateral(sylph_ctx* c, const float* x, int B, int C, int H, int W, const float* w_host, const float* bias_host, const float* top,

@@ -72,8 +72,6 @@ PROTOTYPES = {
     "sylph_export_tower": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "sylph_bottleneck": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p),
                                  POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
-    "sylph_bottleneck_pair": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p), POINTER(c_void_p),
-                                      POINTER(c_void_p), c_void_p, c_void_p]),
     "sylph_allgather_codes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sylph_comm_unique_id": (c_int, [ctypes.c_char_p]),
     "sylph_comm_init_rank": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_int, POINTER(c_void_p)]),

@@ -567,21 +567,6 @@ class Engine:
               "bottleneck")
         return y
 
-    def bottleneck_pair(self, x, ws, scales, shifts):
-        """Two consecutive identity bottleneck blocks through the backbone's own launches (res3 / res4 shapes in bf16: the dual-output
-        conv3 -> conv1' kernel between them).  ws / scales / shifts: conv1, conv2, conv3 of block 0, then of block 1.  -> (y0, y1)."""
-        self._stream()
-        x = x.to(self.device, torch.float32).contiguous()
-        B, C, H, W = x.shape
-        mid = ws[0].shape[0]
-        keep = [[t.detach().cpu().float().contiguous() for t in lst[:6]] for lst in (ws, scales, shifts)]
-        arrs = [(c_void_p * 6)(*[t.data_ptr() for t in lst]) for lst in keep]
-        y0 = torch.empty(B, C, H, W, device=self.device)
-        y1 = torch.empty(B, C, H, W, device=self.device)
-        check(self.L.sylph_bottleneck_pair(self._ctx, _ptr(x), B, C, H, W, mid, arrs[0], arrs[1], arrs[2], _ptr(y0), _ptr(y1)),
-              "bottleneck_pair")
-        return y0, y1
-
     def fpn_lateral(self, x, w, bias, top=None):
         """One FPN lateral (1x1 conv + bias [+ nearest-2x upsampled `top`]) through the backbone's own launch."""
         self._stream()

@@ -180,67 +180,6 @@ def test_bottleneck_blocks_pinned_at_production_shape(case):
     _assert_ulps(y, want, name, max_ulp=2.0, max_frac=0.03, floor="rms")
 
 
-PAIRS = [
-    # name, C, mid, H, W, batch (>= 1024 row tiles: the launch-size rule that selects the dual kernel at B = 64)
-    ("res3 identity pair (conv_dual_kernel<128>)", 512, 128, 100, 168, 8),
-    ("res4 identity pair (conv_dual_kernel<256>)", 1024, 256, 50, 84, 32),
-]
-
-
-@pytest.mark.parametrize("case", PAIRS, ids=["res3_pair", "res4_pair"])
-def test_identity_block_pairs_pinned_at_production_shape(case):
-    """Two consecutive identity blocks of res3 / res4 at their 800x1344 map size through the backbone's launches: conv1, conv2, ONE
-    conv_dual_kernel (conv3 + residual + ReLU of block 0 whose y rows feed conv1 + ReLU of block 1 from registers), conv2, conv3 --
-    against the bf16-storage oracle of the two blocks.  y0 (the dual kernel's first output) as a single block: <= 2 ulps; y1 goes
-    through six bf16 roundings on top of y0's noise."""
-    from oracle import bf16 as OB16
-    name, C, mid, h, w, B = case
-    g = torch.Generator().manual_seed(C + 7 * mid)
-    x = OB16.r(F.relu(torch.randn(B, C, h, w, generator=g)))
-    p0, p1 = _block_params(g, C, mid, C, False), _block_params(g, C, mid, C, False)
-    eng = _engine("bf16")
-    y0, y1 = eng.bottleneck_pair(x, p0[0] + p1[0], p0[1] + p1[1], p0[2] + p1[2])
-    want0 = OB16.bottleneck(x, p0[0], p0[1], p0[2], 1)
-    _assert_ulps(y0, want0, name + " y0", max_ulp=2.0, max_frac=0.03, floor="rms")
-    # block 1 on the HIP graph's own y0: pins conv1' (the second GEMM of the dual kernel) + conv2 + conv3 of block 1
-    want1 = OB16.bottleneck(y0.cpu(), p1[0], p1[1], p1[2], 1)
-    _assert_ulps(y1, want1, name + " y1", max_ulp=2.0, max_frac=0.03, floor="rms")
-
-
-def test_dual_kernel_on_ragged_tiles_equals_unfused_pair():
-    """SYLPH_FUSE_DUAL=2 forces the dual kernel on a small ragged map (27 x 19 = 513 rows per image: the last 128-row tile of every
-    image holds ONE row; 3 images: the tile count is not a multiple of the 8-block walk) in a child process; its two outputs against
-    the unfused launches (SYLPH_FUSE_DUAL=0) of the same pair: y0 to isolated 1-ulp flips (same operands and rounding points, the K
-    walk starts at a different phase), y1 to bf16 rounding of conv1's re-ordered fp32 sums."""
-    import subprocess, sys, os, tempfile
-    child = r"""
-import sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
-from test_bf16_pinned_gpu import _engine, _block_params
-from oracle import bf16 as OB16
-mid = int(sys.argv[4]); C = 4 * mid
-g = torch.Generator().manual_seed(99 + mid)
-x = OB16.r(F.relu(torch.randn(3, C, 27, 19, generator=g)))
-p0, p1 = _block_params(g, C, mid, C, False), _block_params(g, C, mid, C, False)
-y0, y1 = _engine("bf16").bottleneck_pair(x, p0[0] + p1[0], p0[1] + p1[1], p0[2] + p1[2])
-np.savez(sys.argv[3], y0=y0.cpu().numpy(), y1=y1.cpu().numpy())
-"""
-    for mid in (128, 256):
-        outs = {}
-        with tempfile.TemporaryDirectory() as td:
-            for mode in ("2", "0"):
-                path = os.path.join(td, f"m{mode}.npz")
-                r = subprocess.run([sys.executable, "-c", child, os.path.join(ROOT, "sylph-few-shot-detection_amd"), os.path.join(ROOT, "tests"),
-                                    path, str(mid)], env=dict(os.environ, SYLPH_FUSE_DUAL=mode), cwd=ROOT, capture_output=True, text=True, timeout=600)
-                assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-                outs[mode] = np.load(path)
-        a0, b0 = torch.from_numpy(outs["2"]["y0"]), torch.from_numpy(outs["0"]["y0"])
-        a1, b1 = torch.from_numpy(outs["2"]["y1"]), torch.from_numpy(outs["0"]["y1"])
-        assert torch.isfinite(a0).all() and torch.isfinite(a1).all()
-        _assert_ulps(a0, b0, f"dual<{mid}> y0 vs unfused", max_ulp=1.0, max_frac=0.002, floor="rms")
-        _assert_ulps(a1, b1, f"dual<{mid}> y1 vs unfused", max_ulp=2.0, max_frac=0.03, floor="rms")
-
-
 LATERALS = [("fpn_lateral5", 2048, 25, 42, False, 32), ("fpn_lateral4 (+ top-down)", 1024, 50, 84, True, 16),
             ("fpn_lateral3 (+ top-down)", 512, 100, 168, True, 4)]
 
