@@ -311,6 +311,10 @@ def main():
             torch.cuda.synchronize()
             many_way[f"N{nway}"] = round(16 * 8 / (time.perf_counter() - ts), 1)
         eng_m.close()
+    config_legs = None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        eng.close()  # the headline engine's plans (about 10 GB) are not needed any more
+        config_legs = baseline_config_legs(args, device, local_rank)
     if rank == 0 and world == 1 and not args.no_parity:
         parity = parity_bf16(sd, queries[:2], cls_conv, cls_bias, dets[:2])
     if world > 1:
@@ -389,6 +393,8 @@ def main():
             out["support_path"] = support_leg
         if many_way is not None:
             out["many_way"] = many_way
+        if config_legs is not None:
+            out.update(config_legs)
         if parity is not None:
             out["parity_bf16"] = parity
         if world == 1 and not args.no_cpu_baseline:
@@ -396,6 +402,101 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def baseline_config_legs(args, device, local_rank):
+    """Untimed extras (same JSON line): the OTHER BASELINE.json configurations on one GPU, each with its own work count --
+      c2_r50_20way_10shot : configs[2]  R-50-FPN, COCO 20 novel classes, 10-shot, batch 16 queries of 800x1333
+      c4_r101_866way      : configs[3]  R-101-FPN, LVIS freq + common = 866 classes, 5-shot (4 330 support images per episode),
+                                         64 queries of 800x1333 per step (one rank's share of the 8-GPU job; the code all-gather is not in it)
+      c5_roi_encoder_337way: configs[4] ROI-Encoder code generator + CondConvBlock head, LVIS rare = 337 classes, 5-shot, 800x1200 queries
+    Per leg: img_s (query steps, two in flight, codes resident), support_img_s (steady-state support batches of 12 classes through
+    backbone -> code generator), gflop_per_image = the library's own 2 M N K count over the conv launches of a query step,
+    roofline_frac = that work / the summed HIP-event time of those launches / the dense bf16 peak.  Synthetic codes at scale 1.5
+    (random-weight generators give no usable score distribution): ~5 % of the scores pass the 0.05 threshold."""
+    from sylph_amd import synthetic as W
+    from sylph_amd.engine import Engine
+    from sylph_amd.runner import MetaFCOSROIEncoderRunner, create_cfg
+
+    def run_leg(cfg, sd, B, H, Wd, nway, shots, topk, code_scale=1.5, steps=6):
+        cfg.MODEL.FCOS.POST_NMS_TOPK_TEST = topk
+        e = Engine(cfg, dtype=args.dtype, device=local_rank)
+        e.load_state_dict(sd)
+        q = dev_images(B, H, Wd, 11, device)
+        cw = cb = None
+
+        def launch():
+            e.preprocess(q); e.backbone(); e.head(cw, cb)
+            return e.decode_launch()
+
+        def run(n):
+            pend, out = [], None
+            for _ in range(n):
+                pend.append(launch())
+                if len(pend) >= 2:
+                    out = e.decode_fetch(pend.pop(0))
+            while pend:
+                out = e.decode_fetch(pend.pop(0))
+            return out
+        # synthetic codes: the largest of a few scales whose candidate count fits the decode buffers (1 / 8 of all scores per level)
+        for scale in (code_scale, 1.0, 0.7, 0.5):
+            cm = W.synthetic_codes(nway, seed=3, scale=scale)
+            cw, cb = cm["cls_conv"].to(device), cm["cls_bias"].to(device)
+            try:
+                run(3)
+                code_scale = scale
+                break
+            except RuntimeError as ex:
+                if "candidate capacity" not in str(ex):
+                    raise
+        else:
+            raise RuntimeError("no synthetic code scale fits the candidate buffers")
+        e.profile_enable(True); e.profile_read()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        dets = run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - ts
+        prof = e.profile_read()
+        e.profile_enable(False)
+        res = {"img_s": round(B * steps / dt, 1), "batch": B, "image": [H, Wd], "ways": nway, "shots": shots, "code_scale": code_scale,
+               "gflop_per_image": round(prof["conv_flops"] / (B * steps) / 1e9, 2),
+               "roofline_frac": round(prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if prof["conv_ms"] > 0 else None,
+               "detections_per_image": round(sum(int(d["scores"].numel()) for d in dets) / len(dets), 1)}
+        # support path of the same model: 12 classes x shots images per batch (fewer when the images are few)
+        ncls = max(1, 60 // shots)
+        sup = dev_images(ncls * shots, H, Wd, 4200 + shots, device)
+        bxs = torch.cat([W.synthetic_boxes(shots, H, Wd, seed=5200 + c) for c in range(ncls)])
+
+        def sup_step():
+            e.preprocess(sup); e.backbone()
+            return e.codegen_classes(bxs, shots)
+        sup_step()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(4):
+            sup_step()
+        torch.cuda.synchronize()
+        res["support_img_s"] = round(4 * ncls * shots / (time.perf_counter() - ts), 1)
+        res["support_images_per_episode"] = nway * shots
+        res["episode_support_s"] = round(nway * shots / res["support_img_s"], 3)
+        e.close()
+        return res
+
+    legs = {}
+    legs["c2_r50_20way_10shot"] = run_leg(make_cfg(), W.synthetic_state_dict(0, depth=50), 16, args.height, args.width, 20, 10, 100, steps=12)
+    legs["c2_r50_20way_10shot"]["config"] = "BASELINE configs[2]: R-50-FPN COCO 20 novel classes, 10-shot, batch 16 queries"
+    legs["c4_r101_866way"] = run_leg(make_cfg(), W.synthetic_state_dict(0, depth=101), 64, args.height, args.width, 866, 5, 300)
+    legs["c4_r101_866way"]["config"] = ("BASELINE configs[3]: R-101-FPN LVISv1 Meta-FCOS, 866-way 5-shot; one rank's query share of the 8-GPU job "
+                                        "(the code all-gather over xGMI is not part of a query step)")
+    runner = MetaFCOSROIEncoderRunner()
+    cfg5 = create_cfg(runner.get_default_cfg(), "sylph://LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml", ["MODEL.META_LEARN.EVAL_SHOT", 5])
+    sd5 = {}
+    sd5.update(W.backbone_state_dict(0, depth=50)); sd5.update(W.head_state_dict(1, num_classes=60)); sd5.update(W.roi_encoder_state_dict(seed=4))
+    legs["c5_roi_encoder_337way"] = run_leg(cfg5, sd5, 64, 800, 1200, 337, 5, 300)
+    legs["c5_roi_encoder_337way"]["config"] = ("BASELINE configs[4]: ROI-Encoder code generator + CondConvBlock head (Meta-FCOS-ROI-Encoder-finetune.yaml), "
+                                               "LVIS rare 337-way 5-shot, 800x1200 queries; one rank's share of the 4-GPU job")
+    return legs
 
 
 def pmc_per_kernel_bytes(batch):

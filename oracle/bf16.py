@@ -14,7 +14,7 @@ Storage points restated here:
     (conv_igemm / conv_pw / conv_hpipe / bottleneck64[p] / stem_pool), weights bf16, un-scaled
   * a block with a projection shortcut: conv3 and the shortcut are ONE GEMM over K = [t2 | x]; the two
     FrozenBN scales are folded into the weights in fp32 BEFORE the bf16 cast, the shifts are summed
-    (sylph_api.hip make_c3sc)
+    (api_weights.hip make_c3sc)
   * FPN lateral (+ nearest-2x top-down), output convs, P6, relu(P6), P7: bias epilogue -> bf16
   * FCOS towers: conv + bias -> bf16 (stored PRE-GroupNorm); GroupNorm statistics from the fp32 epilogue
     values (before rounding); the consumer applies x <- bf16(relu(fma(a, x, b))) to the stored bf16 values

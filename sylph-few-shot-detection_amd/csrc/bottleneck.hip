@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 //   * x has 64 channels: a halo is 192 rows x 128 B = 24 KiB, so TWO halo buffers fit and the next patch's halo is issued at
 //     the top of a tile, a whole tile ahead (the identity block can only issue it after conv1);
 //   * no residual registers: conv3 and the projection are ONE GEMM over K = [t2 | x] (128) against the packed c3sc weights
-//     ([256][128], both FrozenBN scales folded in fp32 before the bf16 rounding, shifts summed -- sylph_api.hip), the x half of
+//     ([256][128], both FrozenBN scales folded in fp32 before the bf16 rounding, shifts summed -- api_weights.hip), the x half of
 //     the A operand is read straight from the halo's centre rows;  y = relu(acc + shift).
 namespace {
 constexpr int PX_BYTES = XROWS * 128;         // one halo buffer

@@ -13,7 +13,7 @@
 
 #include "../../include/sylph_hip.h"
 
-hipStream_t sylph_internal_stream(sylph_ctx* c);  // sylph_api.hip
+hipStream_t sylph_internal_stream(sylph_ctx* c);  // api_core.hip
 int sylph_internal_fail(const std::string& m);     // sets sylph_last_error(), returns 1
 
 namespace {

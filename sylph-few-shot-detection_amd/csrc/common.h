@@ -69,7 +69,12 @@ struct ConvArgs {
   const struct PwDesc* pw_desc;  // conv_pw.hip: one 64-byte descriptor per M tile (read through the scalar cache)
   const float* pw_table;      // conv_pw.hip: [n_ntiles][scale BN | shift BN] fp32
   int pw_rot_mask;            // set by launch_conv_pw
+  int ksplit;                 // conv_igemm.hip split K: > 1 = grid.y K ranges, fp32 partial planes in `out` (plane stride split_stride elements)
+  long long split_stride;
 };
+
+// one segment of a split-K finish pass: rows [src_row0, +nrows) of the partial planes -> rows [dst_row0, ..) of the output
+struct SplitSeg { int src_row0, dst_row0, res_row0, nrows; };
 
 // conv_pw.hip tile descriptor (two s_load_dwordx8): geometry of the tile's segment + the tile's first row
 struct PwDesc { int row0, seg_rows, out_W, out_row0, in_row0, in_W, in2_row0, in2_W, res_row0, res_W, pad[6]; };
@@ -138,6 +143,8 @@ __device__ __forceinline__ void lds_barrier() {
 // conv_igemm.hip
 int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipStream_t s);
 void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
+int launch_splitk_finish(const float* partial, int ksplit, size_t plane, int ld, int Cout, const SplitSeg* segs_dev, int nseg, int max_rows,
+                         const float* scale, const float* shift, const void* res, int res_ld, int relu_nch, void* out, int out_ld, hipStream_t s);
 // conv_hpipe.hip: 256x256 deep-pipelined halo-operand 3x3 kernel (BM == BN == 256 selects it in launch_conv; the tile
 // table then holds PAIRS of patches and n_mtiles counts the pairs)
 bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   // HALO (3x3 s1 p1): the M tile is an 8 x 16 patch of output positions; its 10 x 18 input halo (192 LDS rows with the
   // tail of the last load round) is loaded ONCE per 64-channel slice and the 9 taps read shifted rows of it.
   // The patch shape (ph x pw <= BM positions, (ph + 2) * (pw + 2) <= HALLOC halo rows) is chosen per segment on the host
-  // (sylph_api.hip pick_patch: 10 x 12 for the 100 x 168 / 50 x 84 maps, 8 x 16 for 200 x 336, ...).
+  // (api_conv.hip pick_patch: 10 x 12 for the 100 x 168 / 50 x 84 maps, 8 x 16 for 200 x 336, ...).
   constexpr int HALLOC = 184;                          // LDS rows reserved for the halo (whole 8-row wave loads)
   constexpr int HRND = (HALLOC + NT / 8 - 1) / (NT / 8);
   constexpr int STAGE = HALO ? (BN + HALLOC) * 128 : (BM + BN) * 128;
@@ -164,6 +164,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   const int cpt2 = in2 ? a.Cin2 / BK : 0;
   const int nk = ntaps * cpt + cpt2;
   const int Ktot = ntaps * Cin + (in2 ? a.Cin2 : 0);
+  // Split K (small launches whose K loop is latency-bound and whose tiles do not fill the chip): blockIdx.y owns the K-slices
+  // [kt0, kt1) and writes its fp32 partial sums to its own plane of a.out; splitk_finish_kernel adds the planes in a fixed order
+  // and applies the epilogue.  Host guarantees (add_conv): no halo mode, no second K source, fp32 out, identity epilogue.
+  int kt0 = 0, kt1 = nk;
+  if (a.ksplit > 1) {
+    kt0 = (int)((long)blockIdx.y * nk / a.ksplit);
+    kt1 = (int)((long)(blockIdx.y + 1) * nk / a.ksplit);
+  }
 
   int abase[AR], abase2[AR];
   uint32_t amask[AR];
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   for (int j = 0; j < BR; ++j) bbase[j] = (size_t)(nt * BN + r0 + RS * j) * Ktot + cl * EPC;
 
   int tap = 0, cc = 0, kh = 0, kw = 0;  // state of the NEXT slice to fetch
+  if (kt0 > 0) { tap = kt0 / cpt; cc = kt0 - tap * cpt; kh = tap / KW; kw = tap - kh * KW; }  // split K: taps outer, channel slices inner
   auto issue = [&](int buf) {
     if constexpr (HALO) {
       // LDS: [B tile][halo].  Slice order: 64-channel slice outer, taps inner; the halo is fetched on tap 0.
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   };
 
   if (NBUF == 1) {
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
       const int hoff = ((kh * HW2 + kw) << 8) | ((kh * HPW + kw) & 15);  // halo row offset (and swizzle-key shift) of the tap about to be fetched
       issue(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -368,9 +377,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) issue(buf ^ 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      if (kt + 1 < kt1) issue(buf ^ 1);
       compute(buf, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   float* const sC = reinterpret_cast<float*>(smem);
   constexpr int TPR = BN / 8;     // lanes per output row
   constexpr int RPP = NT / TPR;   // rows per sweep
-  OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out);
+  OutT* __restrict__ out = reinterpret_cast<OutT*>(a.out) + (a.ksplit > 1 ? (size_t)blockIdx.y * (size_t)a.split_stride : (size_t)0);
   const T* __restrict__ res = reinterpret_cast<const T*>(a.res);
   const int c8 = tid % TPR, rr = tid / TPR;
   const int n0 = nt * BN + c8 * 8;
@@ -609,7 +618,50 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
   if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO>;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WGM * WGN * 64), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(WGM * WGN * 64), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+// Second half of a split-K conv: out[dst row][n] = epilogue(sum over the planes, in plane order, of partial[plane][src row][n]) --
+// v = fma(sum, scale, shift) (+ residual of the output geometry) (ReLU) -> bf16, the rounding points of the unsplit epilogue.
+// One thread = 8 channels of one row; blockIdx.y = segment.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int ksplit, size_t plane, int ld, int Cout,
+                                                            const SplitSeg* __restrict__ segs, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const bf16_t* __restrict__ res, int res_ld,
+                                                            int relu_nch, bf16_t* __restrict__ out, int out_ld) {
+  const SplitSeg sg = segs[blockIdx.y];
+  const int cpr = Cout >> 3;  // 8-channel chunks per row
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int row = idx / cpr, n0 = (idx - row * cpr) * 8;
+  if (row >= sg.nrows) return;
+  const float* src = partial + (size_t)(sg.src_row0 + row) * ld + n0;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  for (int k = 0; k < ksplit; ++k) {
+    const float4 lo = *reinterpret_cast<const float4*>(src + k * plane), hi = *reinterpret_cast<const float4*>(src + k * plane + 4);
+    v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = v[e] * (scale ? scale[n0 + e] : 1.f) + (shift ? shift[n0 + e] : 0.f);
+  if (res) {
+    float rv[8];
+    load8<bf16_t>(res + (size_t)(sg.res_row0 + row) * res_ld + n0, rv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (n0 + e < relu_nch) v[e] = v[e] > 0.f ? v[e] : 0.f;
+  store8<bf16_t>(out + (size_t)(sg.dst_row0 + row) * out_ld + n0, v);
+}
+
+int launch_splitk_finish(const float* partial, int ksplit, size_t plane, int ld, int Cout, const SplitSeg* segs_dev, int nseg, int max_rows,
+                         const float* scale, const float* shift, const void* res, int res_ld, int relu_nch, void* out, int out_ld, hipStream_t s) {
+  if ((Cout & 7) || (ld & 3) || (out_ld & 7) || (res && (res_ld & 7)) || nseg < 1) return -1;
+  const long n = (long)max_rows * (Cout >> 3);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n + 255) / 256), nseg), dim3(256), 0, s, partial, ksplit, plane, ld, Cout, segs_dev, scale,
+                     shift, (const bf16_t*)res, res_ld, relu_nch, (bf16_t*)out, out_ld);
   return (int)hipGetLastError();
 }
 
@@ -694,8 +746,9 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
   if (a.Cin % bk != 0) return -4;
   if (a.in2 && (a.Cin2 % bk != 0 || a.KH * a.KW != 1)) return -6;
   if (!a.zeros) return -5;
+  if (a.ksplit > 1 && (a.halo || a.in2 || !out_f32 || a.stem || a.gn_partial || a.res_mode != 0 || g_nbuf != 1)) return -10;
   if (dt == DT_BF16) {
-    if (a.halo) {  // 3x3 s1 p1 with patch tiles (sylph_api.hip builds the matching tile table)
+    if (a.halo) {  // 3x3 s1 p1 with patch tiles (api_conv.hip builds the matching tile table)
       if (g_nbuf != 1 || BM != 128 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.stem || a.in2) return -9;
       if (BN == 32) {  // narrow prediction convs (bbox/ctrness, code-generator heads): fp32 or bf16 out
         return out_f32 ? launch_cfg<bf16_t, float, 128, 32, 4, 1, 1, false, true>(a, s)

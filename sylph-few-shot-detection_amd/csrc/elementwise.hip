@@ -56,7 +56,7 @@ int launch_preprocess(DType dt, const ImageDesc* imgs_dev, void* out, int B, int
 // Pillow semantics (Resample.c, 8 bits per channel), reproduced bit for bit: two separable passes, horizontal first, each
 // with a triangle filter whose support is scaled by the down-sampling factor (antialiasing), coefficients normalised per
 // output pixel and rounded to 22-bit fixed point, the horizontal result ROUNDED TO uint8 before the vertical pass.
-// The coefficient tables are built on the host in double exactly as Pillow does (sylph_api.hip pil_bilinear_coeffs); this
+// The coefficient tables are built on the host in double exactly as Pillow does (api_backbone.hip pil_bilinear_coeffs); this
 // kernel does the integer arithmetic: out = clip8((2^21 + sum_j kv[j] * clip8((2^21 + sum_i kh[i] * px) >> 22)) >> 22).
 __device__ __forceinline__ int clip8(int v) {
   v >>= 22;

@@ -306,6 +306,40 @@ def test_full_episode_matches_oracle_f32(full_sd):
         np.testing.assert_array_equal(gv["pred_classes"].cpu().numpy(), wv["pred_classes"].numpy())
 
 
+def _keys_of_ordinals(ords, H, W, N):
+    """HIP candidate ordinals -> {(level, location index, class)}."""
+    base, bases = 0, []
+    h, w = H // 8, W // 8
+    for _ in range(5):
+        bases.append(base)
+        base += h * w
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = set()
+    for o in np.asarray(ords).tolist():
+        cls, lc = int(o) % N, int(o) // N
+        lvl = max(l for l in range(5) if bases[l] <= lc)
+        out.add((lvl, lc - bases[lvl], cls))
+    return out
+
+
+def _prove_residue(heads_a, keys_a, heads_b, keys_b, i, what, eps_val, eps_iou, rel=False, **decode_kw):
+    """Every detection that only ONE of two pipelines reports for image i must sit within tolerance of a decision boundary of the
+    pipeline that lacks it (oracle.decode.explain_absence: the 0.05 threshold, the per-level top-1000 cut, the post-NMS top-k cut, an
+    IoU at 0.6 / a score-order flip with its suppressor, or a suppressor that is itself such a case).  -> histogram of the reasons."""
+    from collections import Counter
+    from oracle import decode as OD
+    reasons, bad = Counter(), []
+    for missing_in, heads, keys, other in (("b", heads_b, keys_a - keys_b, keys_a), ("a", heads_a, keys_b - keys_a, keys_b)):
+        for k in sorted(keys):
+            reason, margin, ok = OD.explain_absence(heads, i, k, other, eps_val, eps_iou, rel, **decode_kw)
+            reasons[reason] += 1
+            if not ok or reason == "present":
+                bad.append((missing_in, k, reason, margin))
+    print(f"{what}: {len(keys_a ^ keys_b)} differing detections, all marginal: {dict(reasons)}" if not bad else f"{what}: UNEXPLAINED {bad}")
+    assert not bad, f"{what}: detections that differ without sitting on a decision boundary: {bad}"
+    return reasons
+
+
 def _cand_ordinals(inst, H, W, N):
     """(level, location, class) ordinal used by the HIP path, from oracle fields."""
     base, bases = 0, []
@@ -581,6 +615,49 @@ def test_c4_shape_runs_bf16_full_size():
         assert float(b[:, 2].max()) <= 1333.0 + 1e-3 and float(b[:, 3].max()) <= 800.0 + 1e-3
 
 
+def test_c4_full_size_f32_matches_oracle():
+    """BASELINE config C4 against the ORACLE at full size: R-101-FPN, 866 classes, POST_NMS_TOPK 300, one 800x1333
+    query, fp32 mode.  (1) logits / reg / ctrness / iou of all 22 400 locations x 866 classes within 1e-3 of the CPU oracle;
+    (2) the oracle decoder on the HIP head outputs yields IDENTICAL candidates (exact ordinals: threshold over 19.4 M scores,
+    per-level top-1000 of > 1000 candidates, class-aware NMS, top-300 + ties); (3) end to end >= 97 % of the oracle's detections
+    with the same (level, location, class) and every differing one proved marginal."""
+    from oracle import backbone as OB, decode as OD, head as OH
+    from sylph_amd import synthetic as W
+    if any(k.startswith(("SYLPH_CONV", "SYLPH_FUSE", "SYLPH_GN_FUSE")) for k in os.environ):
+        pytest.skip("default kernel selection only")
+    sd = W.synthetic_state_dict(0, depth=101)
+    cfg = _cfg(**{"MODEL.RESNETS.DEPTH": 101, "MODEL.FCOS.POST_NMS_TOPK_TEST": 300})
+    eng = _engine("f32", cfg)
+    eng.load_state_dict(sd)
+    q = W.synthetic_images(1, 800, 1333, seed=21)
+    codes = W.synthetic_codes(866, seed=22, scale=1.5)
+    x, sizes = OB.preprocess(q)
+    with torch.no_grad():
+        ref_head = OH.fcos_head(OB.backbone_fpn(x, sd, 101), sd, codes)
+    eng.preprocess(q)
+    eng.backbone()
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    hip_head = [[t.cpu() for t in ts] for ts in eng.export_head()]
+    got = eng.decode()[0]
+    for name, hs, rs in zip(("logits", "reg", "ctrness", "iou"), hip_head, ref_head):  # (1)
+        for l in range(5):
+            err = (hs[l] - rs[l]).abs().max().item()
+            assert err <= 1e-3, f"{name} level {l}: max err {err}"
+    assert int((hip_head[0][0][0].sigmoid() > 0.05).sum()) > 1000, "the case must exercise the per-level top-k"
+    wh = OD.detector_postprocess(OD.predict_proposals(*hip_head, post_nms_topk=300)[0], sizes[0], sizes[0][0], sizes[0][1])  # (2)
+    assert got["scores"].numel() == wh["scores"].numel() >= 300
+    np.testing.assert_array_equal(got["cand_index"].cpu().numpy(), _cand_ordinals(wh, 800, 1344, 866))
+    np.testing.assert_allclose(got["scores"].cpu().numpy(), wh["scores"].numpy(), atol=1e-5)
+    np.testing.assert_allclose(got["pred_boxes"].cpu().numpy(), wh["pred_boxes"].numpy(), atol=1e-3)
+    wv = OD.detector_postprocess(OD.predict_proposals(*ref_head, post_nms_topk=300)[0], sizes[0], sizes[0][0], sizes[0][1])  # (3)
+    ref_ord, hip_ord = _cand_ordinals(wv, 800, 1344, 866), got["cand_index"].cpu().numpy()
+    hit = np.isin(ref_ord, hip_ord)
+    print(f"C4 full-size fp32: {hit.sum()} of {hit.size} oracle detections reproduced exactly")
+    assert hit.mean() >= 0.97, hit.mean()
+    _prove_residue(ref_head, _keys_of_ordinals(ref_ord, 800, 1344, 866), hip_head, _keys_of_ordinals(hip_ord, 800, 1344, 866), 0,
+                   "C4 full-size fp32", eps_val=1e-3, eps_iou=5e-3, post_nms_topk=300)
+
+
 def test_c5_query_shape_runs_bf16():
     """BASELINE config C5 query geometry: 800x1200 queries (padded to 800x1216: level widths 152/76/38/19/10, not
     multiples of the 16-wide halo patches), 337 classes."""
@@ -699,8 +776,11 @@ def test_full_size_f32_matches_oracle(full_sd):
       (2) decode + NMS + top-k + postprocess: the oracle decoder run on the HIP head outputs yields IDENTICAL candidates
           (exact index equality; scores 1e-5, boxes 1e-3 px);
       (3) end to end (two fp32 conv stacks with different summation orders feeding threshold / IoU > 0.6 / top-100
-          decisions): >= 95 % of the oracle's detections are reproduced with the same (level, location, class), their
-          scores within 1e-3 and boxes within the stride-relative bound."""
+          decisions): >= 97 % of the oracle's detections are reproduced with the same (level, location, class), their
+          scores within 1e-3 and boxes within the stride-relative bound -- and EVERY detection that only one side reports is
+          PROVED marginal (_prove_residue): on the head outputs of the side that lacks it, it fails exactly one decision, by at
+          most 1e-3 on cls x quality (the bound of (1)) or 5e-3 on an IoU (a 1e-3 x stride error of one box edge against a box
+          at least a stride wide)."""
     from oracle import backbone as OB, decode as OD, head as OH
     from sylph_amd import synthetic as W
     if any(k.startswith(("SYLPH_CONV", "SYLPH_FUSE", "SYLPH_GN_FUSE")) for k in os.environ):
@@ -735,7 +815,9 @@ def test_full_size_f32_matches_oracle(full_sd):
         pos = {int(o): k for k, o in enumerate(hip_ord)}
         hit = np.array([o in pos for o in ref_ord.tolist()])
         print(f"full-size fp32 image {i}: {hit.sum()} of {hit.size} oracle detections reproduced exactly")
-        assert hit.mean() >= 0.95, hit.mean()
+        assert hit.mean() >= 0.97, hit.mean()
+        _prove_residue(ref_head, _keys_of_ordinals(ref_ord, 800, 1344, 5), hip_head, _keys_of_ordinals(hip_ord, 800, 1344, 5), i,
+                       f"full-size fp32 image {i}", eps_val=1e-3, eps_iou=5e-3)
         sel = np.array([pos[int(o)] for o in ref_ord[hit].tolist()])
         np.testing.assert_allclose(gv["scores"].cpu().numpy()[sel], wv["scores"].numpy()[hit], atol=1e-3)
         _assert_boxes(gv["pred_boxes"].cpu().numpy()[sel], wv["pred_boxes"].numpy()[hit], wv["fpn_levels"].numpy()[hit], f"image {i}")
