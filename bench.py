@@ -486,7 +486,9 @@ def baseline_config_legs(args, device, local_rank):
     legs = {}
     legs["c2_r50_20way_10shot"] = run_leg(make_cfg(), W.synthetic_state_dict(0, depth=50), 16, args.height, args.width, 20, 10, 100, steps=12)
     legs["c2_r50_20way_10shot"]["config"] = "BASELINE configs[2]: R-50-FPN COCO 20 novel classes, 10-shot, batch 16 queries"
-    legs["c4_r101_866way"] = run_leg(make_cfg(), W.synthetic_state_dict(0, depth=101), 64, args.height, args.width, 866, 5, 300)
+    cfg4 = make_cfg()
+    cfg4.MODEL.RESNETS.DEPTH = 101
+    legs["c4_r101_866way"] = run_leg(cfg4, W.synthetic_state_dict(0, depth=101), 64, args.height, args.width, 866, 5, 300)
     legs["c4_r101_866way"]["config"] = ("BASELINE configs[3]: R-101-FPN LVISv1 Meta-FCOS, 866-way 5-shot; one rank's query share of the 8-GPU job "
                                         "(the code all-gather over xGMI is not part of a query step)")
     runner = MetaFCOSROIEncoderRunner()
@@ -499,39 +501,51 @@ def baseline_config_legs(args, device, local_rank):
     return legs
 
 
+def _pmc_file():
+    """The committed PMC summary of THIS build (tools/collect_profiles.sh -> tools/rocpd_pmc.py), or (None, reason): a summary whose
+    kernel-source fingerprint differs from the tree is measured on other kernels and is refused -- loudly, no fall-back to older rounds."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rocpd_pmc_fingerprint import csrc_fingerprint
+    path = os.path.join(ROOT, "profiles", "r4_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/r4_pmc_hbm_traffic.json is missing"
+    with open(path) as f:
+        d = json.load(f)
+    if d.get("csrc_fingerprint") != csrc_fingerprint():
+        return None, (f"profiles/r4_pmc_hbm_traffic.json was collected on other kernel sources (fingerprint {d.get('csrc_fingerprint')} != "
+                      f"{csrc_fingerprint()}): re-run tools/collect_profiles.sh")
+    return d, "profiles/r4_pmc_hbm_traffic.json"
+
+
 def pmc_per_kernel_bytes(batch):
     """HBM bytes per step and kernel from the committed PMC passes (same command; scaled by batch), keyed by kernel name."""
-    for name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            with open(path) as f:
-                d = json.load(f)
-            out = {}
-            for k, v in d.get("per_kernel_hbm_bytes_per_image", {}).items():
-                kk = k
-                for tag in ("conv_igemm_kernel", "conv_pw_kernel", "conv_hpipe_kernel<true>", "conv_hpipe_kernel<false>", "bottleneck64p_kernel",
-                            "bottleneck64_kernel", "stem_pool_kernel", "gn_logits_kernel", "gn_taps_kernel"):
-                    if tag in k:
-                        kk = tag
-                        break
-                out[kk] = out.get(kk, 0) + v * batch
-            return out
-    return {}
+    d, _ = _pmc_file()
+    if d is None:
+        return {}
+    out = {}
+    for k, v in d.get("per_kernel_hbm_bytes_per_image", {}).items():
+        kk = k
+        for tag in ("conv_igemm_kernel", "conv_pw_kernel", "conv_hpipe_kernel<true>", "conv_hpipe_kernel<false>", "bottleneck64p_kernel",
+                    "bottleneck64_kernel", "stem_pool_kernel", "gn_logits_kernel", "gn_taps_kernel"):
+            if tag in k:
+                kk = tag
+                break
+        out[kk] = out.get(kk, 0) + v * batch
+    return out
 
 
 def pmc_traffic_per_launch(batch, launches_per_step):
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (separate runs of this same command, as the
-    guide prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE calibrated on preprocess_kernel; tools/rocpd_pmc.py).
+    guide prescribes: FETCH_SIZE doubled on gfx950, WRITE_SIZE calibrated on the first kernel of the step; tools/rocpd_pmc.py).
     Scaled from the profiled batch to this run's batch (traffic is per image).  Returns (bytes or None, source label)."""
-    for name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_f_pmc_hbm_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path) and launches_per_step > 0:
-            with open(path) as f:
-                d = json.load(f)
-            return round(d["hbm_bytes_per_image"] * batch / launches_per_step), {
-                "file": "profiles/" + name, "profiled_batch": d.get("batch"), "hbm_bytes_per_image": round(d["hbm_bytes_per_image"]),
-                "note": "separate rocprofv3 --pmc passes of this command (not collected in this run)"}
-    return None, None
+    d, src = _pmc_file()
+    if d is None or launches_per_step <= 0:
+        print(f"bench.py: roofline.traffic = null: {src}", file=sys.stderr)
+        return None, {"stale_or_missing": src}
+    return round(d["hbm_bytes_per_image"] * batch / launches_per_step), {
+        "file": src, "profiled_batch": d.get("batch"), "hbm_bytes_per_image": round(d["hbm_bytes_per_image"]),
+        "csrc_fingerprint": d.get("csrc_fingerprint"),
+        "note": "separate rocprofv3 --pmc passes of this command on these kernel sources (not collected in this run)"}
 
 
 def parity_bf16(sd, queries, cls_conv, cls_bias, dets):

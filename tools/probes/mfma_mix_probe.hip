@@ -36,14 +36,15 @@ __global__ __launch_bounds__(512, 1) void probe(int iters, const char* __restric
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   // conflict-free fragment addresses: lane l reads 16 bytes at row l (64-byte pitch, swizzled chunk), as the conv kernels do
   const unsigned fbase = lds0 + (lane & 31) * 64 + ((((lane >> 5)) ^ ((lane >> 2) & 3)) << 4) + wave * 256;
-  const char* gp = gsrc + ((size_t)blockIdx.x * 32768 + tid * 16) % (4u << 20);
+  const char* gp = gsrc + tid * 16;  // + a block- and phase-dependent offset below, wrapped inside the 4-MiB buffer
   for (int q = 0; q < iters; ++q) {
     if (MODE >= 2) {  // 3 x 1 KiB per wave into ring stage q & 3; the stage issued two phases ago must have landed
       char* dst = smem + 65536 + (q & 3) * 24576 + wave * 3072;
-      const char* src = gp + (size_t)((q * 24576) & ((4u << 20) - 1));
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + j * 8192), (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+      for (int j = 0; j < 3; ++j) {
+        const unsigned off = ((unsigned)blockIdx.x * 32768u + (unsigned)q * 24576u + (unsigned)j * 8192u) & ((4u << 20) - 1);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gp + off), (lds_ptr_t)(dst + j * 1024), 16, 0, 0);
+      }
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
 #pragma unroll

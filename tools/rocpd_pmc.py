@@ -8,8 +8,13 @@ step (from its first kernel on: preprocess_kernel, or stem_pool_kernel when the 
 KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE is
 used as is (checked here against the step's first kernel, whose write volume is known exactly)."""
 import json
+import os
 import sqlite3
 import sys
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocpd_pmc_fingerprint import csrc_fingerprint  # noqa: E402
 
 
 def last_step(dbfile, counter):
@@ -37,7 +42,7 @@ write, n2, pre_w, write_all, write_by = last_step(sys.argv[2], "WRITE_SIZE")
 B = int(sys.argv[3])
 assert n1 == n2, (n1, n2)
 out = {
-    "batch": B, "conv_launches_per_step": n1,
+    "batch": B, "conv_launches_per_step": n1, "csrc_fingerprint": csrc_fingerprint(),
     "fetch_bytes_raw_per_step": fetch, "fetch_bytes_corrected_per_step": 2.0 * fetch, "write_bytes_per_step": write,
     "hbm_bytes_per_image": (2.0 * fetch + write) / B,
     "hbm_bytes_per_launch": (2.0 * fetch + write) / n1,
