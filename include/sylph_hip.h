@@ -68,6 +68,9 @@ typedef struct sylph_config {
                               (support_set_cls_weight: conv3x3 256->1 + global average pool; code_generator.py:583-613,766-777) */
   int cg_has_scale;        /* len(CODE_GENERATOR.SCALE_LAYER) != 0: per-class weight norm "cls_weight_norm"
                               (support_set_cls_scale: conv3x3 256->1 + global average pool; code_generator.py:615-645,976-993) */
+  int num_share_convs;     /* MODEL.FCOS.NUM_SHARE_CONVS: layers of the shared tower in front of the cls / bbox towers (fcos.py:397,626) */
+  int tower_norm;          /* MODEL.FCOS.NORM: 0 "GN" (and "NaiveGN": adet's NaiveGroupNorm is the same arithmetic), 1 "none": the
+                              towers are (conv3x3 + bias, ReLU) x n, nn.Sequential conv index 2 i instead of 3 i (fcos.py:72-122,399) */
 } sylph_config;
 
 /* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */

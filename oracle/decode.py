@@ -40,10 +40,14 @@ def compute_locations(h: int, w: int, stride: int) -> torch.Tensor:
 
 def decode_level(locations: torch.Tensor, logits: torch.Tensor, reg: torch.Tensor, ctr: torch.Tensor,
                  iou: torch.Tensor, pre_nms_thresh: float = 0.05, pre_nms_topk: int = 1000,
-                 thresh_with_ctr: bool = False, box_quality: Sequence[str] = ("ctrness",)) -> List[Dict]:
-    """fcos_outputs.py:904-1008.  ``reg`` is already multiplied by the level stride (:786)."""
+                 thresh_with_ctr: bool = False, box_quality: Sequence[str] = ("ctrness",), owd: bool = False) -> List[Dict]:
+    """fcos_outputs.py:904-1008.  ``reg`` is already multiplied by the level stride (:786).  owd: MODEL.PROPOSAL_GENERATOR.OWD
+    (:913-916): the class probabilities are replaced by ONE all-ones class."""
     N, C, H, W = logits.shape
     p = logits.permute(0, 2, 3, 1).reshape(N, -1, C).sigmoid()
+    if owd:
+        p = torch.ones_like(p)[:, :, [0]]
+        C = 1
     box_reg = reg.view(N, 4, H, W).permute(0, 2, 3, 1).reshape(N, -1, 4)
     c = ctr.view(N, 1, H, W).permute(0, 2, 3, 1).reshape(N, -1).sigmoid()
     q = iou.view(N, 1, H, W).permute(0, 2, 3, 1).reshape(N, -1).sigmoid()
@@ -134,7 +138,7 @@ def select_over_all_levels(inst: Dict, nms_thresh: float = 0.6, post_nms_topk: i
 
 def predict_proposals(logits, regs, ctrs, ious, strides=(8, 16, 32, 64, 128), pre_nms_thresh=0.05,
                       pre_nms_topk=1000, nms_thresh=0.6, post_nms_topk=100, thresh_with_ctr=False,
-                      box_quality=("ctrness",)) -> List[Dict]:
+                      box_quality=("ctrness",), owd=False) -> List[Dict]:
     """fcos_outputs.py:743-812.  Per image dict: pred_boxes, scores, pred_classes, locations,
     fpn_levels (+ loc_index, cand_index = index into the concatenated pre-NMS candidate list)."""
     per_level = []
@@ -142,7 +146,7 @@ def predict_proposals(logits, regs, ctrs, ious, strides=(8, 16, 32, 64, 128), pr
         h, w = o.shape[-2:]
         loc = compute_locations(h, w, strides[level])
         res = decode_level(loc, o, r * strides[level], c, q, pre_nms_thresh, pre_nms_topk,
-                           thresh_with_ctr, box_quality)
+                           thresh_with_ctr, box_quality, owd)
         for d in res:
             d["fpn_levels"] = torch.full((d["scores"].numel(),), level, dtype=torch.long)
         per_level.append(res)

@@ -21,12 +21,15 @@ GN_EPS = 1e-5
 HEAD_PREFIX = "proposal_generator.fcos_head"
 
 
-def tower(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, num_convs: int = 4) -> torch.Tensor:
-    """fcos.py:72-122.  nn.Sequential indices: conv 3i, GN 3i+1, ReLU 3i+2."""
+def tower(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, num_convs: int = 4, norm: str = "GN") -> torch.Tensor:
+    """fcos.py:72-122.  nn.Sequential indices with MODEL.FCOS.NORM "GN" / "NaiveGN" (adet NaiveGroupNorm: the same arithmetic): conv 3i,
+    GN 3i+1, ReLU 3i+2; with "none": conv 2i, ReLU 2i+1."""
+    step = 2 if norm in ("none", "", None) else 3
     for i in range(num_convs):
-        x = F.conv2d(x, sd[f"{prefix}.{3 * i}.weight"], sd[f"{prefix}.{3 * i}.bias"], padding=1)
-        x = F.group_norm(x, GN_GROUPS, sd[f"{prefix}.{3 * i + 1}.weight"],
-                         sd[f"{prefix}.{3 * i + 1}.bias"], eps=GN_EPS)
+        x = F.conv2d(x, sd[f"{prefix}.{step * i}.weight"], sd[f"{prefix}.{step * i}.bias"], padding=1)
+        if step == 3:
+            x = F.group_norm(x, GN_GROUPS, sd[f"{prefix}.{3 * i + 1}.weight"],
+                             sd[f"{prefix}.{3 * i + 1}.bias"], eps=GN_EPS)
         x = F.relu(x)
     return x
 
@@ -58,15 +61,16 @@ def cond_conv_block(feature, weight, bias=None, scales: Optional[List[float]] = 
 def fcos_head(features: List[torch.Tensor], sd: Dict[str, torch.Tensor], class_codes: Dict[str, torch.Tensor],
               num_cls_convs: int = 4, num_box_convs: int = 4, use_scale: bool = True,
               use_bias: bool = True, cond_block: bool = False, prefix: str = HEAD_PREFIX,
-              cond_scales: Optional[List[float]] = None):
+              cond_scales: Optional[List[float]] = None, num_share_convs: int = 0, norm: str = "GN"):
     """fcos.py:582-667 with support_set_per_class_code given.  Returns per-level lists
     (logits (B,N,h,w), reg (B,4,h,w) = relu(scale_l * bbox_pred), ctrness (B,1,h,w), iou (B,1,h,w))."""
     w = class_codes["cls_conv"]
     b = class_codes["cls_bias"]
     logits, regs, ctrs, ious = [], [], [], []
     for level, feat in enumerate(features):
-        cls_t = tower(feat, sd, f"{prefix}.cls_tower", num_cls_convs)
-        box_t = tower(feat, sd, f"{prefix}.bbox_tower", num_box_convs)
+        feat = tower(feat, sd, f"{prefix}.share_tower", num_share_convs, norm)  # fcos.py:626 (identity for NUM_SHARE_CONVS = 0)
+        cls_t = tower(feat, sd, f"{prefix}.cls_tower", num_cls_convs, norm)
+        box_t = tower(feat, sd, f"{prefix}.bbox_tower", num_box_convs, norm)
         if cond_block:
             logit = cond_conv_block(cls_t, w, b, scales=cond_scales)  # Scale parameters of the checkpoint (head_utils.py:131-136)
         else:

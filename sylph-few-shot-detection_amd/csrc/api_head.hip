@@ -61,11 +61,25 @@ int build_head(sylph_ctx* c, Plan* P) {
   RET(ensure_gn_ws(c, P, nseg > P->B ? nseg : P->B, max_rows));
   const std::vector<SegDesc> segs = pyramid_segs(c, P);
   auto& ops = P->head_ops;
+  const bool tower_gn = c->cfg.tower_norm == 0;  // MODEL.FCOS.NORM "GN"; otherwise "none": conv + bias + ReLU layers
+  const void* tower_in = P->F;                    // what the cls / bbox towers read: the pyramid, or the shared tower's output
   auto tower = [&](int which, const std::vector<ConvLayer>& convs, const std::vector<GNLayer>& gns, void* b0, void* b1,
                    void** last, const float2** coef_last, OpFn* apply_last) -> int {
     const bool defer_last = coef_last != nullptr;
-    const void* in = P->F;
+    const void* in = tower_in;
     void* out = b0;
+    if (!tower_gn) {  // no norm layer: the ReLU is the conv epilogue's
+      for (size_t i = 0; i < convs.size(); ++i) {
+        ConvOpts o; o.pad = 1; o.relu_nch = 1 << 30;
+        RET(add_conv(c, ops, convs[i], in, 256, out, 256, segs, o));
+        if (which < 2) { P->tap_out[which].push_back(out); P->tap_coef[which].push_back(nullptr); }
+        in = out;
+        out = (out == b0) ? b1 : b0;
+        if (c->debug_taps && i + 1 < convs.size()) RET(c->dalloc(&out, rows * 256 * e));
+      }
+      *last = const_cast<void*>(in);
+      return 0;
+    }
     // GroupNorm + ReLU of layers 0 .. n-2 are applied by the NEXT layer's conv to its input halo in LDS (conv_hpipe.hip):
     // no separate streaming pass over those tensors.  The last layer keeps its apply pass (its readers are the
     // prediction convs and the class-conditional 1x1 conv).
@@ -83,8 +97,7 @@ int build_head(sylph_ctx* c, Plan* P) {
       RET(add_conv_gn(c, ops, convs[i], in, 256, out, segs, o, gns[i], 1, defer ? &coef : nullptr, (is_last && defer_last) ? &apply : nullptr));
       if (is_last && defer_last) { *coef_last = coef; *apply_last = apply; }
       coef_prev = coef;
-      P->tap_out[which].push_back(out);
-      P->tap_coef[which].push_back(coef);
+      if (which < 2) { P->tap_out[which].push_back(out); P->tap_coef[which].push_back(coef); }
       in = out;
       out = (out == b0) ? b1 : b0;
       if (c->debug_taps && !is_last) RET(c->dalloc(&out, rows * 256 * e));  // keep every layer's output (same kernels, other destination)
@@ -126,8 +139,16 @@ int build_head(sylph_ctx* c, Plan* P) {
     // the cls tower's last GroupNorm is left to sylph_fcos_head (fused into the class-conditional conv when N <= 32)
     static const int gn_logits_on = getenv("SYLPH_FUSE_GN_LOGITS") ? atoi(getenv("SYLPH_FUSE_GN_LOGITS")) : 1;
     P->cls_coef = nullptr; P->cls_apply = nullptr;
-    const bool defer = gn_logits_on && c->dt == DT_BF16;
+    const bool defer = gn_logits_on && c->dt == DT_BF16 && tower_gn;
     OpFn cls_apply;
+    if (!c->share_tower.empty()) {
+      // MODEL.FCOS.NUM_SHARE_CONVS (fcos.py:397,626): a shared tower in front of both; its last norm is applied in place (two readers)
+      void *s0 = nullptr, *s1 = nullptr, *share_out = nullptr;
+      RET(c->dalloc(&s0, rows * 256 * e));
+      RET(c->dalloc(&s1, rows * 256 * e));
+      RET(tower(2, c->share_tower, c->share_gn, s0, s1, &share_out, nullptr, nullptr));
+      tower_in = share_out;
+    }
     // Small batches (SylphPredictor and the reference's query loop run batch 1, meta_learn_evaluation.py:421-426, predictor.py:248-274):
     // a tower layer is a launch of a few hundred blocks whose K loop is latency-bound, and the two towers are independent chains of
     // four such launches -> the bbox tower (+ its prediction pass) runs on a second stream between a fork and a join event, the cls

@@ -100,7 +100,8 @@ struct sylph_ctx {
   struct Block { ConvLayer c1, c2, c3, sc, c3sc; bool has_sc = false, fused_sc = false; };
   std::vector<std::vector<Block>> stages;  // res2..res5
   ConvLayer fpn_lat[3], fpn_out[3], p6, p7;  // index 0..2 = stage 3..5
-  std::vector<ConvLayer> cls_tower, box_tower;
+  std::vector<ConvLayer> cls_tower, box_tower, share_tower;  // share_tower: MODEL.FCOS.NUM_SHARE_CONVS layers in front of both
+  std::vector<GNLayer> share_gn;
   std::vector<GNLayer> cls_gn, box_gn;
   std::vector<ConvLayer> pair_tower;  // cls|bbox towers stacked on Cout (layer 0 shares the input, then grouped)
   std::vector<GNLayer> pair_gn;

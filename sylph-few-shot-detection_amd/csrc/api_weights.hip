@@ -246,14 +246,18 @@ int sylph_finalize_weights(sylph_ctx* c) {
   if (has_prefix(c, hp + ".cls_tower") || has_prefix(c, hp + ".bbox_tower")) {
     c->cls_tower.resize(c->cfg.num_cls_convs); c->cls_gn.resize(c->cfg.num_cls_convs);
     c->box_tower.resize(c->cfg.num_box_convs); c->box_gn.resize(c->cfg.num_box_convs);
-    for (int i = 0; i < c->cfg.num_cls_convs; ++i) {
-      RET(make_conv_bias(c, {hp + ".cls_tower." + std::to_string(3 * i)}, &c->cls_tower[i]));
-      RET(make_gn(c, hp + ".cls_tower." + std::to_string(3 * i + 1), &c->cls_gn[i]));
-    }
-    for (int i = 0; i < c->cfg.num_box_convs; ++i) {
-      RET(make_conv_bias(c, {hp + ".bbox_tower." + std::to_string(3 * i)}, &c->box_tower[i]));
-      RET(make_gn(c, hp + ".bbox_tower." + std::to_string(3 * i + 1), &c->box_gn[i]));
-    }
+    c->share_tower.resize(c->cfg.num_share_convs); c->share_gn.resize(c->cfg.num_share_convs);
+    // nn.Sequential indices of a tower (fcos.py:72-122): conv 3 i, norm 3 i + 1, ReLU 3 i + 2 -- without a norm layer conv 2 i, ReLU 2 i + 1
+    const bool gn = c->cfg.tower_norm == 0;
+    const int step = gn ? 3 : 2;
+    struct { const char* name; std::vector<ConvLayer>* convs; std::vector<GNLayer>* gns; int n; } towers[3] = {
+        {".cls_tower.", &c->cls_tower, &c->cls_gn, c->cfg.num_cls_convs}, {".bbox_tower.", &c->box_tower, &c->box_gn, c->cfg.num_box_convs},
+        {".share_tower.", &c->share_tower, &c->share_gn, c->cfg.num_share_convs}};
+    for (auto& t : towers)
+      for (int i = 0; i < t.n; ++i) {
+        RET(make_conv_bias(c, {hp + t.name + std::to_string(step * i)}, &(*t.convs)[i]));
+        if (gn) RET(make_gn(c, hp + t.name + std::to_string(step * i + 1), &(*t.gns)[i]));
+      }
     const int pair_on = SYLPH_AB_ENV("SYLPH_PAIR_TOWERS", 0);  // A/B knob (-DSYLPH_ABLATE builds only)
     // Pairing (both towers as ONE grouped launch per layer) paid +2 % with the pre-halo kernel (the A tile was shared by
     // four N tiles); with halo tiles the separate towers are 1 % faster (1 666-1 672 vs 1 645-1 660 img/s), so it is opt-in.

@@ -34,12 +34,16 @@ def config_from_cfg(cfg) -> SylphConfig:
     sc.stride_in_1x1 = int(bool(m.RESNETS.get("STRIDE_IN_1X1", True)))
     sc.num_cls_convs = int(f.NUM_CLS_CONVS)
     sc.num_box_convs = int(f.NUM_BOX_CONVS)
-    if int(f.NUM_SHARE_CONVS) != 0:
-        raise NotImplementedError("MODEL.FCOS.NUM_SHARE_CONVS != 0 is not supported")
+    sc.num_share_convs = int(f.NUM_SHARE_CONVS)
     if bool(f.USE_DEFORMABLE):
         raise NotImplementedError("MODEL.FCOS.USE_DEFORMABLE is not supported")
-    if str(f.NORM) != "GN":
-        raise NotImplementedError("MODEL.FCOS.NORM must be 'GN'")
+    norm = "" if f.NORM is None else str(f.NORM)
+    if norm in ("GN", "NaiveGN"):  # adet's NaiveGroupNorm computes GroupNorm(32, C) by hand: the same arithmetic
+        sc.tower_norm = 0
+    elif norm in ("none", ""):     # fcos.py:399: "none" -> no norm layer: conv + ReLU towers
+        sc.tower_norm = 1
+    else:
+        raise NotImplementedError(f"MODEL.FCOS.NORM {norm!r}: 'GN', 'NaiveGN' and 'none' are supported (the per-level BatchNorm variants are not)")
     strides = list(f.FPN_STRIDES)
     sc.nlevels = len(strides)
     for i, s in enumerate(strides):
@@ -76,8 +80,6 @@ def config_from_cfg(cfg) -> SylphConfig:
     # knobs that change the reference arithmetic and are not implemented must fail loudly, not be ignored
     if int(m.RESNETS.get("RES5_DILATION", 1)) != 1:
         raise NotImplementedError("MODEL.RESNETS.RES5_DILATION != 1 is not supported")
-    if bool(m.PROPOSAL_GENERATOR.get("OWD", False)):
-        raise NotImplementedError("MODEL.PROPOSAL_GENERATOR.OWD is not supported")
     if bool(cg.ROI_BOX.get("FPN_MULTILEVEL_FEATURE", False)):
         raise NotImplementedError("CODE_GENERATOR.ROI_BOX.FPN_MULTILEVEL_FEATURE is not supported")
     # (USE_PER_CLS_SCALE is set by the LVIS yamls but never read by the reference; INIT_NORM_LAYER only affects initialisation)
@@ -162,6 +164,8 @@ class Engine:
         self.cond_scale = 1.0  # CondConvBlock Scale of the first chunk (ROIEncoder head), read from the checkpoint
         self.cond_scales = [1.0]  # all CondConvBlock Scales (one per 256-channel chunk of the class code)
         self._cond_scales_loaded = False  # did the checkpoint carry cond_cls_logits.scales.*?
+        # MODEL.PROPOSAL_GENERATOR.OWD (fcos_outputs.py:913-916): class probabilities are replaced by ONE all-ones class
+        self.owd = bool(cfg.MODEL.PROPOSAL_GENERATOR.get("OWD", False)) if cfg is not None else False
         self._batch = None  # (B, H, W, [(h,w)...])
         self._ncls = 0
         self._keep = []  # tensors that must outlive queued kernels
@@ -283,6 +287,15 @@ class Engine:
         self._stream()
         assert cls_conv.dim() == 4, f"Weight has dimension: {cls_conv.dim()}"
         assert cls_conv.size(2) == 1 and cls_conv.size(3) == 1
+        if self.owd:
+            # `logits_pred = ones_like(logits_pred)[:, :, [0]]` after the sigmoid: one class whose probability is exactly 1 -- a zero
+            # code with bias 40 (sigmoid(40) rounds to 1.0f) through the same class-conditional conv; the towers / box heads are unchanged
+            if getattr(self, "_owd_codes", None) is None:
+                self._owd_codes = (torch.zeros(1, 256, device=self.device), torch.full((1,), 40.0, device=self.device))
+            w1, b1 = self._owd_codes
+            self._ncls = 1
+            check(self.L.sylph_fcos_head(self._ctx, _ptr(w1), _ptr(b1), 1), "fcos_head (OWD)")
+            return
         # The codes of an episode are the same tensors for every query batch: their packed fp32 form is kept (no cast / reshape /
         # scale kernels in the steady-state step) until a different tensor, or a modified one, arrives.
         # Writes the library does through raw pointers (normalize_codes in place, ...) do not bump tensor._version: the engine

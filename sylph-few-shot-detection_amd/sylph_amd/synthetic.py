@@ -74,15 +74,25 @@ def backbone_state_dict(seed: int = 0, depth: int = 50) -> Dict[str, torch.Tenso
 
 
 def head_state_dict(seed: int = 1, num_classes: int = 60, c: int = 256, num_convs: int = 4,
-                    levels: int = 5) -> Dict[str, torch.Tensor]:
+                    levels: int = 5, num_share_convs: int = 0, norm: str = "GN") -> Dict[str, torch.Tensor]:
+    """MetaFCOSHead weights under the reference's keys.  norm "GN": a tower is nn.Sequential(conv, GroupNorm, ReLU) x n (indices 3i,
+    3i + 1); norm "none": (conv, ReLU) x n (index 2i) -- fcos.py:72-122.  num_share_convs: the shared tower in front of both."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     p = "proposal_generator.fcos_head"
-    for t in ("cls_tower", "bbox_tower"):
-        for i in range(num_convs):
-            sd[f"{p}.{t}.{3 * i}.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
-            sd[f"{p}.{t}.{3 * i}.bias"] = torch.randn(c, generator=g) * 0.1
-            _gn(g, sd, f"{p}.{t}.{3 * i + 1}", c)
+    step = 3 if norm == "GN" else 2
+    for t, n in (("cls_tower", num_convs), ("bbox_tower", num_convs)):
+        for i in range(n):
+            sd[f"{p}.{t}.{step * i}.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
+            sd[f"{p}.{t}.{step * i}.bias"] = torch.randn(c, generator=g) * 0.1
+            if norm == "GN":
+                _gn(g, sd, f"{p}.{t}.{step * i + 1}", c)
+    g2 = torch.Generator().manual_seed(seed * 7 + 3)  # a separate stream: the keys above stay bit-stable when a shared tower is added
+    for i in range(num_share_convs):
+        sd[f"{p}.share_tower.{step * i}.weight"] = _conv(g2, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
+        sd[f"{p}.share_tower.{step * i}.bias"] = torch.randn(c, generator=g2) * 0.1
+        if norm == "GN":
+            _gn(g2, sd, f"{p}.share_tower.{step * i + 1}", c)
     sd[f"{p}.cls_logits.weight"] = _conv(g, num_classes, c, 1, std=0.01)
     sd[f"{p}.cls_logits.bias"] = torch.full((num_classes,), -math.log(99.0))
     sd[f"{p}.bbox_pred.weight"] = _conv(g, 4, c, 3, std=0.02)

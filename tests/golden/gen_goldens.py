@@ -157,6 +157,43 @@ def gen_decode_variants():
     np.savez_compressed(os.path.join(HERE, "g1b_decode_variants.npz"), **out)
 
 
+def gen_head_variants():
+    """MetaFCOSHead / predict_proposals under config branches the five target yamls leave off (missing #3):
+    MODEL.FCOS.NUM_SHARE_CONVS = 1 (shared tower, fcos.py:397,626), MODEL.FCOS.NORM = "none" (conv + ReLU towers, fcos.py:72-122,399) and
+    MODEL.PROPOSAL_GENERATOR.OWD (one all-ones class, fcos_outputs.py:913-916) -- on g1's feature pyramid.  Separate file: g1 stays bit-stable."""
+    from sylph.modeling.meta_fcos.fcos import MetaFCOS
+    from ref_shim import ShapeSpec
+    shapes = {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(3, 8)}
+    H, Wd, B = 128, 160, 2
+    feats = feature_pyramid(B, H, Wd, seed=11)
+    image_sizes = [(H, Wd - 7), (H - 5, Wd)]
+    codes = W.synthetic_codes(5, seed=35, scale=2.0)
+    out = {"cls_conv": codes["cls_conv"].numpy(), "cls_bias": codes["cls_bias"].numpy(), "image_sizes": np.array(image_sizes)}
+    with torch.no_grad():
+        for tag, share, norm, owd in (("share1", 1, "GN", False), ("nonorm", 0, "none", False), ("share2_nonorm", 2, "none", False),
+                                      ("owd", 0, "GN", True)):
+            cfg = make_cfg()
+            cfg.MODEL.FCOS.NUM_SHARE_CONVS = share
+            cfg.MODEL.FCOS.NORM = norm
+            cfg.MODEL.PROPOSAL_GENERATOR.OWD = owd
+            sd = W.head_state_dict(seed=1, num_classes=60, num_share_convs=share, norm=norm)
+            model = MetaFCOS(cfg, shapes).eval()
+            load_prefixed(model, sd, "proposal_generator")
+            out[f"{tag}_weights_checksum"] = checksum(sd, "proposal_generator")
+            logits, reg, ctr, iou, _, _ = model.fcos_head(feats, None, False, codes)
+            for l in range(5):
+                out[f"{tag}_logits{l}"] = logits[l].numpy()
+                out[f"{tag}_reg{l}"] = reg[l].numpy()
+                out[f"{tag}_ctr{l}"] = ctr[l].numpy()
+            locations = model.compute_locations(feats)
+            props = model.fcos_outputs.predict_proposals(logits, reg, ctr, iou, locations, image_sizes, [])
+            for i, p in enumerate(props):
+                out.update(inst_to_np(p, f"{tag}_img{i}"))
+            out[f"{tag}_count"] = np.array([len(p) for p in props])
+            print("head variant", tag, [len(p) for p in props])
+    np.savez_compressed(os.path.join(HERE, "g1c_head_variants.npz"), **out)
+
+
 def gen_codegen():
     from sylph.modeling.code_generator.code_generator import CodeGenerator
     from ref_shim import Boxes, Instances
@@ -377,7 +414,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
-    for fn in (gen_head_decode, gen_decode_variants, gen_codegen, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_codegen, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
         if not only or fn.__name__ in only:
             fn()
     print("done")

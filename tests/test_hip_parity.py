@@ -130,6 +130,46 @@ def test_head_matches_reference_golden(g1, head_engine, tag):
         np.testing.assert_allclose(io[l].cpu().numpy(), g1[f"iou{l}"], atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag,share,norm,owd", [("share1", 1, "GN", False), ("nonorm", 0, "none", False), ("share2_nonorm", 2, "none", False),
+                                                ("owd", 0, "GN", True)])
+def test_head_variants_match_reference_golden(g1, golden_dir, tag, share, norm, owd, dtype):
+    """Reference branches the five target yamls leave off (missing #3), against goldens generated from the reference
+    (g1c): MODEL.FCOS.NUM_SHARE_CONVS = 1 / 2 (shared tower in front of the cls / bbox towers, fcos.py:397,626), MODEL.FCOS.NORM "none"
+    (conv + ReLU towers, fcos.py:72-122,399) and MODEL.PROPOSAL_GENERATOR.OWD (one all-ones class, fcos_outputs.py:913-916).  fp32: head
+    outputs <= 1e-3 and identical (level, location, class) triples; bf16: head outputs to bf16 tolerance."""
+    from oracle.decode import detector_postprocess
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g1c_head_variants.npz"))
+    cfg = _cfg(**{"MODEL.FCOS.NUM_SHARE_CONVS": share, "MODEL.FCOS.NORM": norm, "MODEL.PROPOSAL_GENERATOR.OWD": owd})
+    eng = _engine(dtype, cfg)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60, num_share_convs=share, norm=norm))
+    sizes = [tuple(int(v) for v in s) for s in g["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.head(torch.from_numpy(g["cls_conv"]), torch.from_numpy(g["cls_bias"]))
+    lo, rg, ct, io = eng.export_head()
+    tol = 1e-3 if dtype == "f32" else 6e-2
+    for l in range(5):
+        if not owd:  # OWD: the conv output is irrelevant (the reference overwrites the probabilities); ours is the constant 40
+            ref = g[f"{tag}_logits{l}"]
+            assert np.abs(lo[l].cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max()), f"logits level {l}"
+        for name, got in (("reg", rg), ("ctr", ct)):
+            ref = g[f"{tag}_{name}{l}"]
+            assert np.abs(got[l].cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max()), f"{name} level {l}"
+    if dtype != "f32":
+        return
+    dets = eng.decode()
+    for i, d in enumerate(dets):
+        pre = f"{tag}_img{i}"
+        ref = {k: torch.from_numpy(g[f"{pre}_{k}"]) for k in ("pred_boxes", "scores", "pred_classes", "fpn_levels", "locations")}
+        ref = detector_postprocess(ref, sizes[i], sizes[i][0], sizes[i][1])
+        assert d["scores"].numel() == ref["scores"].numel() > 0
+        np.testing.assert_array_equal(d["pred_classes"].cpu().numpy(), ref["pred_classes"].numpy())
+        np.testing.assert_array_equal(d["fpn_levels"].cpu().numpy(), ref["fpn_levels"].numpy())
+        np.testing.assert_array_equal(d["locations"].cpu().numpy(), ref["locations"].numpy())
+        np.testing.assert_allclose(d["scores"].cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
+
+
 @pytest.mark.parametrize("tag,thr", [("n1_t50", 0.05), ("n5_t50", 0.05), ("n20_t50", 0.05), ("n20_t11", 0.011)])
 def test_decode_matches_reference_golden(g1, tag, thr):
     """boxes/scores within 1e-3 and identical kept (level, location, class) triples."""

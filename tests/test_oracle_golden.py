@@ -71,6 +71,34 @@ def test_decode_matches_reference(g1, head_sd, tag, thr):
         np.testing.assert_allclose(p["pred_boxes"].numpy(), g1[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
 
 
+HEAD_VARIANTS = [("share1", 1, "GN", False), ("nonorm", 0, "none", False), ("share2_nonorm", 2, "none", False), ("owd", 0, "GN", True)]
+
+
+@pytest.mark.parametrize("tag,share,norm,owd", HEAD_VARIANTS)
+def test_head_variants_match_reference(g1, golden_dir, tag, share, norm, owd):
+    """MODEL.FCOS.NUM_SHARE_CONVS (shared tower, fcos.py:397,626), MODEL.FCOS.NORM "none" (fcos.py:72-122,399) and
+    MODEL.PROPOSAL_GENERATOR.OWD (fcos_outputs.py:913-916) against the reference's own head outputs and proposals (g1c)."""
+    g = _load(golden_dir, "g1c_head_variants.npz")
+    sd = W.head_state_dict(seed=1, num_classes=60, num_share_convs=share, norm=norm)
+    assert abs(_checksum(sd, "proposal_generator") - float(g[f"{tag}_weights_checksum"])) < 1e-3
+    codes = {"cls_conv": torch.from_numpy(g["cls_conv"]), "cls_bias": torch.from_numpy(g["cls_bias"])}
+    logits, regs, ctrs, ious = H.fcos_head(_feats(g1), sd, codes, num_share_convs=share, norm=norm)
+    for l in range(5):
+        np.testing.assert_allclose(logits[l].numpy(), g[f"{tag}_logits{l}"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(regs[l].numpy(), g[f"{tag}_reg{l}"], atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(ctrs[l].numpy(), g[f"{tag}_ctr{l}"], atol=TOL, rtol=TOL)
+    ref = lambda k: [torch.from_numpy(g[f"{tag}_{k}{l}"]) for l in range(5)]
+    props = D.predict_proposals(ref("logits"), ref("reg"), ref("ctr"), ious, owd=owd)
+    for i, p in enumerate(props):
+        pre = f"{tag}_img{i}"
+        assert p["scores"].numel() == int(g[f"{tag}_count"][i])
+        np.testing.assert_array_equal(p["pred_classes"].numpy(), g[f"{pre}_pred_classes"])
+        np.testing.assert_array_equal(p["fpn_levels"].numpy(), g[f"{pre}_fpn_levels"])
+        np.testing.assert_array_equal(p["locations"].numpy(), g[f"{pre}_locations"])
+        np.testing.assert_allclose(p["scores"].numpy(), g[f"{pre}_scores"], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(p["pred_boxes"].numpy(), g[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
+
+
 VARIANTS = [("iou", ["iou"], False), ("ctriou", ["ctrness", "iou"], False), ("ctr_twc", ["ctrness"], True),
             ("iou_twc", ["iou"], True), ("ctriou_twc", ["ctrness", "iou"], True)]
 
