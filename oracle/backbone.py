@@ -10,7 +10,10 @@ on the reference's call sites:
     FrozenBN conversion, backbone call)
   * configs/COCO-Detection/Meta-FCOS/Base-FCOS.yaml:3-11 (build_fcos_resnet_fpn_backbone,
     res3..res5 -> FPN), sylph/runner/adet_configs.py:39 (TOP_LEVELS 2 -> P6,P7 from p5)
-Parity for this file is UNPINNED by the reference (no numeric test exists there).
+Parity for this file is UNPINNED by the reference (no numeric test exists there).  Third-party pins: the ResNet part (stem,
+max-pool, bottleneck blocks incl. STRIDE_IN_1X1, projection shortcuts, FrozenBN) agrees with Hugging Face's independent
+`transformers.ResNetModel(downsample_in_bottleneck=True)` to 2e-5 on res2..res5, R-50 and R-101, ragged sizes
+(tests/test_oracle_vs_hf_resnet.py); the FPN part and P6/P7 by float64 known answers (tests/golden/gen_known_answers.py).
 """
 from typing import Dict, List, Sequence, Tuple
 

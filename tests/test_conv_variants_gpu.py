@@ -68,6 +68,52 @@ def test_parity_suite_with_pointwise_kernel_everywhere():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_parity_suite_with_split_k_and_two_streams_forced():
+    """SYLPH_SPLIT_K=2 splits EVERY eligible bf16 conv_igemm launch along K (fp32 partial planes + splitk_finish_kernel), whatever its
+    tile count or depth -- 1x1 and 3x3, with and without a same-geometry residual, strided -- and SYLPH_HEAD_STREAMS=2 always runs the
+    bbox tower on the second stream: conv2d vs torch, backbone / episode vs the oracle, the full-size and the ulp-level block tests."""
+    env = {"SYLPH_SPLIT_K": "2", "SYLPH_HEAD_STREAMS": "2"}
+    _rerun(env, "conv2d or backbone or episode or c3 or full_size_prop or head")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "bottleneck or detections"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_small_batch_restructuring_is_result_neutral():
+    """Batch 1 (split-K where it pays + two streams, the default) against the same image inside a batch of 8 (neither): identical
+    detections -- same (level, location, class) triples -- and pyramids equal to bf16 rounding of the re-ordered fp32 sums."""
+    child = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from sylph_amd import synthetic as W
+from test_hip_parity import _engine, _cfg
+eng = _engine("bf16", _cfg())
+eng.load_state_dict(W.synthetic_state_dict(0, depth=50))
+imgs = W.synthetic_images(1, 512, 672, seed=17)
+codes = W.synthetic_codes(5, seed=4, scale=3.0)
+eng.preprocess(imgs); eng.backbone(); eng.head(codes["cls_conv"], codes["cls_bias"])
+d = eng.decode()[0]
+np.savez(sys.argv[3], cand=d["cand_index"].cpu().numpy(), scores=d["scores"].cpu().numpy(), *[t.float().cpu().numpy() for t in eng.export_pyramid()])
+"""
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env_extra in (("default", {}), ("plain", {"SYLPH_SPLIT_K": "0", "SYLPH_HEAD_STREAMS": "0"})):
+            path = os.path.join(td, f"{name}.npz")
+            r = subprocess.run([sys.executable, "-c", child, os.path.join(ROOT, "sylph-few-shot-detection_amd"), os.path.join(ROOT, "tests"), path],
+                               env=dict(os.environ, **env_extra), cwd=ROOT, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            z = np.load(path)
+            outs[name] = {k: z[k] for k in z.files}
+    a, b = outs["default"], outs["plain"]
+    for k in [k for k in a if k.startswith("arr_")]:
+        cos = float((a[k] * b[k]).sum() / (np.linalg.norm(a[k]) * np.linalg.norm(b[k]) + 1e-30))
+        err = np.abs(a[k] - b[k]).max() / max(1.0, np.abs(b[k]).max())
+        assert cos > 0.9999 and err < 0.03, f"{k}: cosine {cos}, max rel err {err}"
+    common = np.intersect1d(a["cand"], b["cand"]).size
+    assert a["cand"].size >= 50 and common >= 0.9 * max(a["cand"].size, b["cand"].size), (a["cand"].size, b["cand"].size, common)
+
+
 def test_parity_suite_with_fusions_off():
     """The unfused graph (res2 identity blocks as three launches, stem and max-pool as two, stand-alone GroupNorm applies)
     must pass the same backbone / head / episode checks as the default fused one."""
