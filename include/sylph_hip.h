@@ -71,6 +71,9 @@ typedef struct sylph_config {
   int num_share_convs;     /* MODEL.FCOS.NUM_SHARE_CONVS: layers of the shared tower in front of the cls / bbox towers (fcos.py:397,626) */
   int tower_norm;          /* MODEL.FCOS.NORM: 0 "GN" (and "NaiveGN": adet's NaiveGroupNorm is the same arithmetic), 1 "none": the
                               towers are (conv3x3 + bias, ReLU) x n, nn.Sequential conv index 2 i instead of 3 i (fcos.py:72-122,399) */
+  int cg_tower_gn_mask;    /* CODE_GENERATOR.TOWER_LAYERS[i][0] == "GN"   -> bit i (sylph_config_default: all ones = ["GN", "ReLU"] layers); */
+  int cg_tower_relu_mask;  /* CODE_GENERATOR.TOWER_LAYERS[i][1] == "ReLU" -> bit i.  A layer without norm / activation has no such module
+                              in support_set_shared_tower, whose nn.Sequential indices advance per EXISTING module (code_generator.py:648-688) */
 } sylph_config;
 
 /* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */

@@ -29,24 +29,36 @@ def bias_prior(prior_prob: float = 0.01) -> float:
     return -math.log((1 - prior_prob) / prior_prob)
 
 
-def shared_tower(x: torch.Tensor, sd, n_layers: int = 2, prefix: str = CG_PREFIX) -> torch.Tensor:
-    for i in range(n_layers):
-        x = F.conv2d(x, sd[f"{prefix}.support_set_shared_tower.{3 * i}.weight"],
-                     sd[f"{prefix}.support_set_shared_tower.{3 * i}.bias"], padding=1)
-        x = F.group_norm(x, 32, sd[f"{prefix}.support_set_shared_tower.{3 * i + 1}.weight"],
-                         sd[f"{prefix}.support_set_shared_tower.{3 * i + 1}.bias"], eps=GN_EPS)
-        x = F.relu(x)
+def shared_tower(x: torch.Tensor, sd, n_layers: int = 2, prefix: str = CG_PREFIX, spec=None) -> torch.Tensor:
+    """code_generator.py:648-688.  spec = CODE_GENERATOR.TOWER_LAYERS entries [norm, act] (default n_layers x ["GN", "ReLU"]): norm
+    "GN" / "" (build_fpn_norm), act "ReLU" / "Tanh" / ""; the nn.Sequential index advances per existing module."""
+    spec = spec if spec is not None else [["GN", "ReLU"]] * n_layers
+    idx = 0
+    for norm, act in spec:
+        x = F.conv2d(x, sd[f"{prefix}.support_set_shared_tower.{idx}.weight"],
+                     sd[f"{prefix}.support_set_shared_tower.{idx}.bias"], padding=1)
+        idx += 1
+        if norm == "GN":
+            x = F.group_norm(x, 32, sd[f"{prefix}.support_set_shared_tower.{idx}.weight"],
+                             sd[f"{prefix}.support_set_shared_tower.{idx}.bias"], eps=GN_EPS)
+            idx += 1
+        elif norm not in ("", "none", None):
+            raise NotImplementedError(norm)
+        if act == "ReLU":
+            x = F.relu(x); idx += 1
+        elif act == "Tanh":
+            x = torch.tanh(x); idx += 1
     return x
 
 
 def code_from_roi_features(roi: torch.Tensor, sd, n_tower_layers: int = 2, bias_l2_norm: bool = False,
                            has_bias_layer: bool = True, has_weight_layer: bool = False, has_scale_layer: bool = False,
-                           prefix: str = CG_PREFIX) -> Dict[str, torch.Tensor]:
+                           prefix: str = CG_PREFIX, tower_spec=None) -> Dict[str, torch.Tensor]:
     """roi (S,256,7,7): ALL S shots belong to one class (eval: num_shot = batch,
     code_generator.py:788-792).  Returns un-normalised cls_conv (1,OUT,1,1), cls_bias (1,1,1,1) and, with a SCALE_LAYER,
     cls_weight_norm (1,1,1,1).  WEIGHT_LAYER: softmax over the shots of a pooled 1-channel head replaces the uniform
     shot weights (code_generator.py:583-613,766-777,969-979)."""
-    f = shared_tower(roi, sd, n_tower_layers, prefix)
+    f = shared_tower(roi, sd, n_tower_layers, prefix, tower_spec)
     conv_feat = F.conv2d(f, sd[f"{prefix}.support_set_cls_conv.0.weight"],
                          sd[f"{prefix}.support_set_cls_conv.0.bias"], padding=1)
     conv_feat = F.adaptive_avg_pool2d(conv_feat, (1, 1))
@@ -76,7 +88,9 @@ def code_from_roi_features(roi: torch.Tensor, sd, n_tower_layers: int = 2, bias_
 
 def code_generator(features: List[torch.Tensor], boxes: torch.Tensor, sd, strides=(8, 16, 32, 64, 128),
                    **kw) -> Dict[str, torch.Tensor]:
-    """code_generator.py:924-1002: ROI pool (one box per support image) then the head."""
+    """code_generator.py:924-1002: ROI pool (one box per support image) then the head.  (ROI_BOX.FPN_MULTILEVEL_FEATURE cannot run
+    in the reference: CodeGeneratorHead builds detectron2's single-level-assignment ROIPooler (:26,343), so :943 iterates over the
+    batch dimension of ONE tensor and GroupNorm fails on the unbatched (256, 7, 7) slices.)"""
     roi = roi_pooler(features, boxes, strides, out_size=7)
     return code_from_roi_features(roi, sd, **kw)
 

@@ -39,8 +39,15 @@ int build_support(sylph_ctx* c, Plan* P) {
   const void* in = P->roi;
   void* out = P->cgA;
   for (size_t i = 0; i < c->cg_tower.size(); ++i) {
+    // CODE_GENERATOR.TOWER_LAYERS[i] = [norm, activation] (code_generator.py:648-688): conv3x3 + bias, GroupNorm(32) if "GN", ReLU if "ReLU"
+    const bool gn = (c->cfg.cg_tower_gn_mask >> i) & 1, relu = (c->cfg.cg_tower_relu_mask >> i) & 1;
     ConvOpts o; o.pad = 1;
-    RET(add_conv_gn(c, ops, c->cg_tower[i], in, 256, out, segs, o, c->cg_gn[i], 1));
+    if (gn) {
+      RET(add_conv_gn(c, ops, c->cg_tower[i], in, 256, out, segs, o, c->cg_gn[i], relu ? 1 : 0));
+    } else {
+      if (relu) o.relu_nch = 1 << 30;
+      RET(add_conv(c, ops, c->cg_tower[i], in, 256, out, 256, segs, o));
+    }
     in = out;
     out = (out == P->cgA) ? P->cgB : P->cgA;
   }

@@ -129,6 +129,8 @@ void sylph_config_default(sylph_config* cfg) {
   cfg->head_fc_dim = 512;
   cfg->cg_meta_bias = 0;
   cfg->cg_has_weight = 0; cfg->cg_has_scale = 0;
+  cfg->num_share_convs = 0; cfg->tower_norm = 0;
+  cfg->cg_tower_gn_mask = 0x3fffffff; cfg->cg_tower_relu_mask = 0x3fffffff;  // every TOWER_LAYERS entry is ["GN", "ReLU"]
 }
 
 const char* sylph_last_error(void) { return g_err.c_str(); }

@@ -319,9 +319,15 @@ int sylph_finalize_weights(sylph_ctx* c) {
   const std::string cp = "code_generator.code_generator_head";
   if (has_prefix(c, cp)) {
     c->cg_tower.resize(c->cfg.cg_tower_layers); c->cg_gn.resize(c->cfg.cg_tower_layers);
+    int seq = 0;  // nn.Sequential index: conv, then the norm / activation modules that exist (code_generator.py:648-688)
     for (int i = 0; i < c->cfg.cg_tower_layers; ++i) {
-      RET(make_conv_bias(c, {cp + ".support_set_shared_tower." + std::to_string(3 * i)}, &c->cg_tower[i]));
-      RET(make_gn(c, cp + ".support_set_shared_tower." + std::to_string(3 * i + 1), &c->cg_gn[i]));
+      RET(make_conv_bias(c, {cp + ".support_set_shared_tower." + std::to_string(seq)}, &c->cg_tower[i]));
+      ++seq;
+      if ((c->cfg.cg_tower_gn_mask >> i) & 1) {
+        RET(make_gn(c, cp + ".support_set_shared_tower." + std::to_string(seq), &c->cg_gn[i]));
+        ++seq;
+      }
+      if ((c->cfg.cg_tower_relu_mask >> i) & 1) ++seq;
     }
     RET(make_conv_bias(c, {cp + ".support_set_cls_conv.0"}, &c->cg_cls));
     {

@@ -29,7 +29,7 @@ class SylphConfig(Structure):
         ("cg_conv_l2_norm", c_int), ("cg_use_weight_scale", c_int), ("prior_prob", c_float), ("cand_cap", c_int),
         ("cg_type", c_int), ("tok_num_conv", c_int), ("tok_num_fc", c_int), ("enc_layers", c_int),
         ("head_num_fc", c_int), ("head_fc_dim", c_int), ("cg_meta_bias", c_int), ("cg_has_weight", c_int), ("cg_has_scale", c_int),
-        ("num_share_convs", c_int), ("tower_norm", c_int),
+        ("num_share_convs", c_int), ("tower_norm", c_int), ("cg_tower_gn_mask", c_int), ("cg_tower_relu_mask", c_int),
     ]
 
 

@@ -81,7 +81,9 @@ def config_from_cfg(cfg) -> SylphConfig:
     if int(m.RESNETS.get("RES5_DILATION", 1)) != 1:
         raise NotImplementedError("MODEL.RESNETS.RES5_DILATION != 1 is not supported")
     if bool(cg.ROI_BOX.get("FPN_MULTILEVEL_FEATURE", False)):
-        raise NotImplementedError("CODE_GENERATOR.ROI_BOX.FPN_MULTILEVEL_FEATURE is not supported")
+        # the reference cannot run it either: CodeGeneratorHead builds detectron2's ROIPooler (one output tensor), code_generator.py:943
+        # then iterates over its batch dimension and GroupNorm fails on the unbatched slices
+        raise NotImplementedError("CODE_GENERATOR.ROI_BOX.FPN_MULTILEVEL_FEATURE is not supported (it fails in the reference too)")
     # (USE_PER_CLS_SCALE is set by the LVIS yamls but never read by the reference; INIT_NORM_LAYER only affects initialisation)
     for knob in ("ALL_MASK", "USE_DEFORMABLE", "META_WEIGHT"):
         if bool(cg.get(knob, False)):
@@ -113,10 +115,21 @@ def config_from_cfg(cfg) -> SylphConfig:
     if cg_name != "CodeGenerator":
         raise NotImplementedError(f"{cg.NAME} is not implemented")
     tl = list(cg.TOWER_LAYERS)
-    for layer in tl:
-        if list(layer) != ["GN", "ReLU"]:
-            raise NotImplementedError(f"CODE_GENERATOR.TOWER_LAYERS entry {layer} (only ['GN','ReLU'])")
     sc.cg_tower_layers = len(tl)
+    sc.cg_tower_gn_mask = sc.cg_tower_relu_mask = 0
+    for i, layer in enumerate(tl):  # [norm, activation] (code_generator.py:648-688)
+        norm, act = (list(layer) + ["", ""])[:2]
+        norm, act = ("" if norm is None else str(norm)), ("" if act is None else str(act))
+        if norm in ("GN", "NaiveGN"):
+            sc.cg_tower_gn_mask |= 1 << i
+        elif norm not in ("", "none"):
+            raise NotImplementedError(f"CODE_GENERATOR.TOWER_LAYERS entry {layer}: norm must be 'GN' or '' (LN / BN / IN are not supported)")
+        if act == "ReLU":
+            sc.cg_tower_relu_mask |= 1 << i
+        elif act != "":  # the reference builds nothing for other strings except "Tanh"
+            raise NotImplementedError(f"CODE_GENERATOR.TOWER_LAYERS entry {layer}: activation must be 'ReLU' or ''")
+    if len(tl) > 30:
+        raise NotImplementedError("more than 30 CODE_GENERATOR.TOWER_LAYERS")
     cl = list(cg.CLS_LAYER)
     if len(cl) != 3 or cl[0] not in ("", "none") or cl[1] != "" or int(cl[2]) != 1:
         raise NotImplementedError(f"CODE_GENERATOR.CLS_LAYER {cl} (only ['', '', 1])")

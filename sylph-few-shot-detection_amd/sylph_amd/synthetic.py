@@ -107,16 +107,25 @@ def head_state_dict(seed: int = 1, num_classes: int = 60, c: int = 256, num_conv
 
 
 def codegen_state_dict(seed: int = 2, c: int = 256, out_c: int = 256, tower_layers: int = 2,
-                       levels: int = 5, weight_scale_layers: bool = False) -> Dict[str, torch.Tensor]:
+                       levels: int = 5, weight_scale_layers: bool = False, tower_spec=None) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     sd = {}
     p = "code_generator.code_generator_head"
     for l in range(levels):
         _gn(g, sd, f"{p}.init_norm.{l}", c)
-    for i in range(tower_layers):
-        sd[f"{p}.support_set_shared_tower.{3 * i}.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
-        sd[f"{p}.support_set_shared_tower.{3 * i}.bias"] = torch.randn(c, generator=g) * 0.1
-        _gn(g, sd, f"{p}.support_set_shared_tower.{3 * i + 1}", c)
+    # tower_spec: CODE_GENERATOR.TOWER_LAYERS as [[norm, act], ...] (default: tower_layers x ["GN", "ReLU"]); the nn.Sequential index
+    # advances by one per module that exists (conv, [norm], [act]) -- code_generator.py:648-688
+    spec = tower_spec if tower_spec is not None else [["GN", "ReLU"]] * tower_layers
+    idx = 0
+    for norm, act in spec:
+        sd[f"{p}.support_set_shared_tower.{idx}.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
+        sd[f"{p}.support_set_shared_tower.{idx}.bias"] = torch.randn(c, generator=g) * 0.1
+        idx += 1
+        if norm == "GN":
+            _gn(g, sd, f"{p}.support_set_shared_tower.{idx}", c)
+            idx += 1
+        if act in ("ReLU", "Tanh"):
+            idx += 1
     _gn(g, sd, f"{p}.post_norm", out_c)
     sd[f"{p}.support_set_cls_conv.0.weight"] = _conv(g, out_c, c, 3, std=math.sqrt(1.0 / (9 * c)))
     sd[f"{p}.support_set_cls_conv.0.bias"] = torch.randn(out_c, generator=g) * 0.1

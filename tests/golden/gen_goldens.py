@@ -247,6 +247,44 @@ def gen_codegen():
     np.savez_compressed(os.path.join(HERE, "g3_codegen.npz"), **out)
 
 
+def gen_codegen_variants():
+    """CodeGenerator branches the target yamls leave off (missing #3), on g3's S = 2 / 5 inputs:
+    CODE_GENERATOR.TOWER_LAYERS with entries other than ["GN", "ReLU"] (no norm / no activation / no tower at all,
+    code_generator.py:648-688).  ROI_BOX.FPN_MULTILEVEL_FEATURE is not here because the reference cannot run it: CodeGeneratorHead
+    builds detectron2's ROIPooler (:26,343), whose output is ONE tensor, so :943 iterates over its batch dimension and GroupNorm
+    fails on the unbatched (256, 7, 7) slices."""
+    from sylph.modeling.code_generator.code_generator import CodeGenerator
+    from ref_shim import Boxes, Instances
+    out = {}
+    H, Wd = 192, 256
+    g3 = np.load(os.path.join(HERE, "g3_codegen.npz"))
+    for tag, spec, multi in (("mixed_tower", [["", "ReLU"], ["GN", ""], ["GN", "ReLU"]], False), ("plain_tower", [["", ""]], False),
+                             ("no_tower", [], False)):
+        cfg = make_cfg(False)
+        cg = cfg.MODEL.META_LEARN.CODE_GENERATOR
+        cg.TOWER_LAYERS = spec
+        cg.ROI_BOX.FPN_MULTILEVEL_FEATURE = multi
+        sd = W.codegen_state_dict(seed=2, tower_spec=spec)
+        out[f"{tag}_weights_checksum"] = checksum(sd, "code_generator")
+        gen = CodeGenerator(cfg, 256, 5, cfg.MODEL.FCOS.FPN_STRIDES).eval()
+        load_prefixed(gen, sd, "code_generator")
+        for S in (2, 5):
+            feats = [torch.from_numpy(g3[f"s{S}_feat{l}_q8"].astype(np.float32) / 32.0) for l in range(5)]
+            boxes = torch.from_numpy(g3[f"s{S}_boxes"])
+            insts = []
+            for i in range(S):
+                it = Instances((H, Wd))
+                it.gt_boxes = Boxes(boxes[i:i + 1])
+                it.gt_classes = torch.tensor([3])
+                insts.append(it)
+            with torch.no_grad():
+                code = gen(feats, insts)
+            out[f"{tag}_s{S}_cls_conv"] = code["cls_conv"].numpy()
+            out[f"{tag}_s{S}_cls_bias"] = code["cls_bias"].numpy()
+            print("codegen variant", tag, S, code["cls_conv"].flatten()[:3], code["cls_bias"].flatten())
+    np.savez_compressed(os.path.join(HERE, "g3d_codegen_variants.npz"), **out)
+
+
 def gen_codegen_weight_scale():
     """CODE_GENERATOR.WEIGHT_LAYER (softmax shot weights) and SCALE_LAYER (cls_weight_norm) of the reference's CodeGenerator
     (code_generator.py:583-645,766-829,969-999) on g3's S = 2 / 5 inputs, then forward_normalize_code with the weight norm."""
@@ -414,7 +452,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
-    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_codegen, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_codegen, gen_codegen_variants, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
         if not only or fn.__name__ in only:
             fn()
     print("done")

@@ -975,6 +975,25 @@ def test_codegen_weight_and_scale_layers_match_reference_golden(golden_dir, g3, 
     np.testing.assert_allclose(normed[0, 256], g[f"norm{i}_cls_bias"].reshape(-1)[0], atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag,spec", [("mixed_tower", [["", "ReLU"], ["GN", ""], ["GN", "ReLU"]]), ("plain_tower", [["", ""]]), ("no_tower", [])])
+def test_codegen_tower_variants_match_reference_golden(golden_dir, g3, tag, spec, dtype):
+    """CODE_GENERATOR.TOWER_LAYERS entries other than ["GN", "ReLU"] (no norm / no activation / no tower, code_generator.py:648-688)
+    on the HIP path against the reference's own outputs (g3d): fp32 <= 1e-3, bf16 to bf16 tolerance."""
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g3d_codegen_variants.npz"))
+    eng = _engine(dtype, _cfg(**{"MODEL.META_LEARN.CODE_GENERATOR.TOWER_LAYERS": spec}))
+    assert int(eng.sc.cg_tower_layers) == len(spec)
+    eng.load_state_dict(W.codegen_state_dict(seed=2, tower_spec=spec))
+    for S in (2, 5):
+        eng.import_pyramid(_feats(g3, f"s{S}_feat"), (192, 256))
+        code = eng.codegen(torch.from_numpy(g3[f"s{S}_boxes"])).cpu().numpy()
+        ref_c, ref_b = g[f"{tag}_s{S}_cls_conv"].reshape(-1), float(g[f"{tag}_s{S}_cls_bias"].reshape(-1)[0])
+        tol = 1e-3 if dtype == "f32" else 3e-2
+        assert np.abs(code[:256] - ref_c).max() <= tol * max(1.0, np.abs(ref_c).max()), (tag, S)
+        assert abs(code[256] - ref_b) <= tol * max(1.0, abs(ref_b)), (tag, S)
+
+
 def test_c4_support_path_r101_full_size_bf16():
     """BASELINE config C4 support path at full size: R-101 backbone, LVIS code-generator settings (BIAS_L2_NORM), two classes x 3
     support images of 800x1333 in ONE batch (sylph_codegen_classes), bf16, against the fp32 CPU oracle: cosine of the un-normalised

@@ -198,6 +198,21 @@ def test_roi_encoder_matches_reference(golden_dir, S):
     np.testing.assert_allclose(out["cls_bias"].numpy(), g[f"s{S}_cls_bias"], atol=5e-5, rtol=5e-5)
 
 
+TOWER_VARIANTS = [("mixed_tower", [["", "ReLU"], ["GN", ""], ["GN", "ReLU"]]), ("plain_tower", [["", ""]]), ("no_tower", [])]
+
+
+@pytest.mark.parametrize("S", [2, 5])
+@pytest.mark.parametrize("tag,spec", TOWER_VARIANTS)
+def test_codegen_tower_variants_match_reference(golden_dir, g3, tag, spec, S):
+    """CODE_GENERATOR.TOWER_LAYERS entries other than ["GN", "ReLU"] (code_generator.py:648-688) against the reference module (g3d)."""
+    g = _load(golden_dir, "g3d_codegen_variants.npz")
+    sd = W.codegen_state_dict(seed=2, tower_spec=spec)
+    assert abs(_checksum(sd, "code_generator") - float(g[f"{tag}_weights_checksum"])) < 1e-3
+    out = CG.code_generator(_feats(g3, f"s{S}_feat"), torch.from_numpy(g3[f"s{S}_boxes"]), sd, tower_spec=spec)
+    np.testing.assert_allclose(out["cls_conv"].numpy(), g[f"{tag}_s{S}_cls_conv"], atol=TOL, rtol=TOL)
+    np.testing.assert_allclose(out["cls_bias"].numpy(), g[f"{tag}_s{S}_cls_bias"], atol=TOL, rtol=TOL)
+
+
 @pytest.mark.parametrize("S", [2, 5])
 def test_codegen_weight_and_scale_layers_match_reference(golden_dir, g3, S):
     """CODE_GENERATOR.WEIGHT_LAYER (softmax shot weights) + SCALE_LAYER (cls_weight_norm), code_generator.py:583-645,766-829,969-999,
