@@ -200,6 +200,17 @@ int build_backbone(sylph_ctx* c, Plan* P) {
     P->stage_out[si] = X; P->stage_h[si] = Hin; P->stage_w[si] = Win;
   }
   // FPN (res3..res5 -> p3..p5), top-down with nearest 2x upsample fused as a residual, then P6/P7
+  // Small batches: after lateral5 the FPN is two independent chains of small launches -- {output5, P6, relu, P7} and {lateral4, output4,
+  // lateral3, output3} -- so the first one runs on the context's side stream between a fork and a join (as the bbox tower does,
+  // api_head.hip); large batches keep one stream.
+  static const int fpn_two_on = getenv("SYLPH_HEAD_STREAMS") ? atoi(getenv("SYLPH_HEAD_STREAMS")) : 1;
+  const bool fpn_two = fpn_two_on == 2 || (fpn_two_on == 1 && (size_t)B * P->Ltot <= (size_t)8 * 22400);
+  if (fpn_two && !c->side_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  std::vector<OpFn> side_ops;
   void* lat[3] = {nullptr, nullptr, nullptr};
   for (int k = 2; k >= 0; --k) {
     const int si = k + 1, h = stage_h[si], w = stage_w[si], cin = 256 << si;
@@ -213,11 +224,17 @@ int build_backbone(sylph_ctx* c, Plan* P) {
       if (h != 2 * stage_h[si + 1] || w != 2 * stage_w[si + 1]) return fail("FPN needs exact 2x level sizes");
     }
     RET(add_conv(c, ops, c->fpn_lat[k], stage_out[si], cin, lat[k], 256, segs, ol));
+    if (k == 2 && fpn_two)  // fork right behind lateral5: the side stream continues from here
+      ops.push_back([c](hipStream_t s) {
+        if (hipEventRecord(c->ev_fork, s) != hipSuccess || hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return -101;
+        return 0;
+      });
     std::vector<SegDesc> so = image_segs(B, h, w, h, w);
     for (int b = 0; b < B; ++b) so[b].out_row0 = b * P->Ltot + P->off[k];
     ConvOpts oo; oo.pad = 1;
-    RET(add_conv(c, ops, c->fpn_out[k], lat[k], 256, P->F, 256, so, oo));
+    RET(add_conv(c, (k == 2 && fpn_two) ? side_ops : ops, c->fpn_out[k], lat[k], 256, P->F, 256, so, oo));
   }
+  std::vector<OpFn>& top_ops = fpn_two ? side_ops : ops;  // P6 / P7 hang off output5
   for (int k = 3; k < c->cfg.nlevels && k < 5; ++k) {
     std::vector<SegDesc> sg = image_segs(B, P->hl[k - 1], P->wl[k - 1], P->hl[k], P->wl[k]);
     for (int b = 0; b < B; ++b) {
@@ -238,10 +255,17 @@ int build_backbone(sylph_ctx* c, Plan* P) {
       CopySeg* csd;
       RET(upload(c, (void**)&csd, cs.data(), cs.size() * sizeof(CopySeg)));
       const void* F = P->F;
-      ops.push_back([=](hipStream_t s) { return launch_relu_rows(dt, F, p6r, 256, csd, B, n6, s); });
+      top_ops.push_back([=](hipStream_t s) { return launch_relu_rows(dt, F, p6r, 256, csd, B, n6, s); });
       src = p6r;
     }
-    RET(add_conv(c, ops, k == 3 ? c->p6 : c->p7, src, 256, P->F, 256, sg, op));
+    RET(add_conv(c, top_ops, k == 3 ? c->p6 : c->p7, src, 256, P->F, 256, sg, op));
+  }
+  if (fpn_two) {
+    for (const OpFn& inner : side_ops) ops.push_back([c, inner](hipStream_t) { return inner(c->side_stream); });
+    ops.push_back([c](hipStream_t s) {
+      if (hipEventRecord(c->ev_join, c->side_stream) != hipSuccess || hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) return -102;
+      return 0;
+    });
   }
   P->backbone_built = true;
   return 0;

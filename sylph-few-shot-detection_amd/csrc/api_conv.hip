@@ -287,7 +287,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   const long tiles_all = (long)g.n_mtiles * (L.Cout_pad / BN);
   if (split_on && dt == DT_BF16 && !hpipe && !halo && !pw && !of32 && !o.in2 && !o.stem && !o.want_gn && !o.gn_coef && o.group_cout == 0 &&
       o.mul_nch == 0 && o.cout_override < 0 && L.Cout == L.Cout_pad && (o.relu_nch == 0 || o.relu_nch >= L.Cout) && o.res_mode != 2 &&
-      (o.res_mode == 0 || (o.res_ld & 7) == 0) && L.Cin % 64 == 0 && ((nk_slices >= 32 && tiles_all <= 384) || (split_on == 2 && nk_slices >= 8))) {
+      (o.res_mode == 0 || (o.res_ld & 7) == 0) && L.Cin % 64 == 0 && ((nk_slices >= 32 && tiles_all <= 384) || (nk_slices >= 64 && tiles_all < 768) || (split_on == 2 && nk_slices >= 8))) {
     // Where it pays (B = 1 timeline, profiles/r4_timeline_B1.txt): deep K (>= 32 slices: the 3x3 convs of res4 / res5 / FPN P5..P7, the
     // 2048-channel 1x1s) on at most 1.5 tiles per CU.  Every extra launch costs ~9 us of dispatch latency at batch 1 and the fp32
     // planes are 2 x ks times the bf16 output: shallow-K or many-row layers (res3, the 1x1s of res4) lose, so they are not split.
