@@ -149,7 +149,15 @@ bool use_hpipe(sylph_ctx* c, const ConvLayer& L, const std::vector<SegDesc>& seg
         (o.relu_nch == 0 || o.relu_nch >= cout_l) && L.Cin % 32 == 0 && L.Cout % 256 == 0 && L.Cout == L.Cout_pad))
     return false;
   const long blocks = (patch_count(segs, 128, 256, 4) + 1) / 2 * (L.Cout / 256), rounds = (blocks + 255) / 256;
-  return hp_on == 2 || (blocks >= 512 && blocks * 10 >= rounds * 256 * 8);
+  if (hp_on == 2) return true;
+  if (blocks >= 512) return blocks * 10 >= rounds * 256 * 8;
+  // Small batches (round 4): a launch of fewer than 512 blocks is at most two rounds, i.e. it costs one or two block times (~63 us for
+  // K = 2304) whatever its fill; the alternative -- conv_igemm on 64-row tiles -- walks the same K as a latency-bound chain (~54 us) and,
+  // for a tower layer, adds the GroupNorm finalize + apply launches the fused halo transform makes unnecessary (~40 us at batch 1).
+  // Measured at 800x1333 (tools/sweep_small_batches.py): >= 90 blocks (the FCOS towers from batch 1 on: 94 blocks each, both towers in
+  // one round on two streams) 540 -> 581 img/s at batch 1, 806 -> 914 at batch 2, 1 227 -> 1 280 at batch 4; with the 70-block FPN
+  // P3 output conv of batch 1 included (threshold 64) 574.
+  return blocks >= 90;
 }
 
 int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const void* in, int in_ld, void* out,
