@@ -55,3 +55,33 @@ def test_oracle_resnet_matches_huggingface_resnet(depth, h, w):
         scale = max(1.0, float(b.abs().max()))
         assert err <= 2e-5 * scale, f"{name}: max err {err} at scale {scale}"
     assert np.isfinite(ref[-1].numpy()).all()
+
+
+def test_oracle_nms_matches_greedy_nms_on_huggingface_box_iou():
+    """Class-aware greedy NMS of the oracle (torchvision nms arithmetic restated, oracle/decode.py) against a plain greedy loop over
+    Hugging Face's `box_iou` (transformers/loss/loss_for_object_detection.py: the pairwise-IoU arithmetic of torchvision.ops.box_iou,
+    an independent copy): identical keep lists on random overlapping boxes, many per class, incl. exact score ties."""
+    from transformers.loss.loss_for_object_detection import box_iou
+    from oracle import decode as OD
+    g = torch.Generator().manual_seed(3)
+    n = 600
+    xy = torch.rand(n, 2, generator=g) * 200
+    wh = torch.rand(n, 2, generator=g) * 80 + 4
+    boxes = torch.cat([xy, xy + wh], dim=1)
+    boxes[100:140] = boxes[:40] + torch.rand(40, 4, generator=g) * 3  # near-duplicates: plenty of IoU > 0.6 pairs
+    scores = torch.rand(n, generator=g)
+    scores[200:220] = scores[100:120]  # exact ties
+    classes = torch.randint(0, 4, (n,), generator=g)
+    keep = OD.nms_per_class(boxes.numpy(), scores.numpy(), classes.numpy(), 0.6)
+    iou, _ = box_iou(boxes, boxes)
+    order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+    alive, want = [True] * n, []
+    for a, i in enumerate(order):
+        if not alive[i]:
+            continue
+        want.append(i)
+        for j in order[a + 1:]:
+            if alive[j] and int(classes[j]) == int(classes[i]) and float(iou[i, j]) > 0.6:
+                alive[j] = False
+    assert len(want) < n - 30, "the case must suppress a fair number of boxes"
+    assert keep.tolist() == want
