@@ -285,6 +285,11 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   const DType dt = c->dt;
   const bool of32 = o.out_f32;
   const double flops = o.flops >= 0.0 ? o.flops : 2.0 * (double)rows * (double)a.Cout * (double)(L.KH * L.KW) * (double)L.Cin;
+  static const int nbuf2_on = getenv("SYLPH_CONV_NBUF2") ? atoi(getenv("SYLPH_CONV_NBUF2")) : 1;
+  // 64-row tiles are what conv_pick_tile gives a launch of fewer than 1024 128-row blocks, i.e. one that cannot hide the round trip of
+  // a K-slice behind co-resident blocks: those walk K through TWO LDS stages (the next slice's loads under the current MFMAs).
+  // Measured (tools/sweep_small_batches.py): batch 1 574 -> 606 img/s, batch 2 908 -> 931, batch 8 1 643 -> 1 665.
+  if (nbuf2_on && dt == DT_BF16 && !hpipe && !halo && !pw && BM == 64) a.nbuf2 = 1;
   // ---- split K (small batches: SylphPredictor / the reference's batch-1 query loop, predictor.py:248-274) ------------------------
   // A launch with fewer tiles than CUs walks its whole K range as ONE latency-bound chain per block (load slice -> wait -> MFMA, no
   // co-resident blocks to hide it) while most of the chip idles: res5 conv2 of one 800x1333 image is 96 blocks x 72 slices = 82 us

@@ -761,6 +761,15 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
       return fast ? launch_cfg<bf16_t, bf16_t, 128, 64, 2, 2, 1, true, true>(a, s)
                   : launch_cfg<bf16_t, bf16_t, 128, 64, 2, 2, 1, false, true>(a, s);
     }
+    if (a.nbuf2 && g_nbuf == 1 && BM == 64 && (BN == 128 || BN == 64)) {
+      // small launches (fewer blocks than it takes to hide a slice's round trip by occupancy): two LDS stages, the next slice's loads
+      // in flight under the current slice's MFMAs
+      const bool fast = !out_f32 && fast_ok(a, BN);
+      if (BN == 128) return out_f32 ? launch_cfg<bf16_t, float, 64, 128, 2, 2, 2, false>(a, s)
+                                    : (fast ? launch_cfg<bf16_t, bf16_t, 64, 128, 2, 2, 2, true>(a, s) : launch_cfg<bf16_t, bf16_t, 64, 128, 2, 2, 2, false>(a, s));
+      return out_f32 ? launch_cfg<bf16_t, float, 64, 64, 2, 2, 2, false>(a, s)
+                     : (fast ? launch_cfg<bf16_t, bf16_t, 64, 64, 2, 2, 2, true>(a, s) : launch_cfg<bf16_t, bf16_t, 64, 64, 2, 2, 2, false>(a, s));
+    }
     if (!out_f32 && g_nbuf == 1 && fast_ok(a, BN)) return launch_n<bf16_t, bf16_t, 1, true>(a, BM, BN, s);
     return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);
   }
