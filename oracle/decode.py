@@ -42,7 +42,9 @@ def decode_level(locations: torch.Tensor, logits: torch.Tensor, reg: torch.Tenso
                  iou: torch.Tensor, pre_nms_thresh: float = 0.05, pre_nms_topk: int = 1000,
                  thresh_with_ctr: bool = False, box_quality: Sequence[str] = ("ctrness",), owd: bool = False) -> List[Dict]:
     """fcos_outputs.py:904-1008.  ``reg`` is already multiplied by the level stride (:786).  owd: MODEL.PROPOSAL_GENERATOR.OWD
-    (:913-916): the class probabilities are replaced by ONE all-ones class."""
+    (:913-916): the class probabilities are replaced by ONE all-ones class, and -- :937 ``thresh_with_ctr or OWD`` / :951 ``not
+    thresh_with_ctr and not OWD`` -- the box quality is multiplied in BEFORE the ``> pre_nms_thresh`` test, i.e. the OWD candidates
+    are the locations whose quality alone clears the threshold (round 5: rounds <= 4 thresholded the constant 1)."""
     N, C, H, W = logits.shape
     p = logits.permute(0, 2, 3, 1).reshape(N, -1, C).sigmoid()
     if owd:
@@ -60,11 +62,12 @@ def decode_level(locations: torch.Tensor, logits: torch.Tensor, reg: torch.Tenso
         quality = torch.sqrt(q[:, :, None] * c[:, :, None])
     else:
         raise NotImplementedError()
-    if thresh_with_ctr:
+    quality_first = thresh_with_ctr or owd                      # :937
+    if quality_first:
         p = p * quality
     cand = p > pre_nms_thresh
     top_n = cand.reshape(N, -1).sum(1).clamp(max=pre_nms_topk)
-    if not thresh_with_ctr:
+    if not quality_first:                                       # :951
         p = p * quality
     results = []
     for i in range(N):

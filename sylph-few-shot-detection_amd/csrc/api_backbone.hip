@@ -231,7 +231,7 @@ int build_backbone(sylph_ctx* c, Plan* P) {
       });
     std::vector<SegDesc> so = image_segs(B, h, w, h, w);
     for (int b = 0; b < B; ++b) so[b].out_row0 = b * P->Ltot + P->off[k];
-    ConvOpts oo; oo.pad = 1;
+    ConvOpts oo; oo.pad = 1; oo.stream_slot = (k == 2 && fpn_two) ? 1 : 0;
     RET(add_conv(c, (k == 2 && fpn_two) ? side_ops : ops, c->fpn_out[k], lat[k], 256, P->F, 256, so, oo));
   }
   std::vector<OpFn>& top_ops = fpn_two ? side_ops : ops;  // P6 / P7 hang off output5
@@ -241,7 +241,7 @@ int build_backbone(sylph_ctx* c, Plan* P) {
       sg[b].in_row0 = b * P->Ltot + P->off[k - 1];
       sg[b].out_row0 = b * P->Ltot + P->off[k];
     }
-    ConvOpts op; op.stride = 2; op.pad = 1;
+    ConvOpts op; op.stride = 2; op.pad = 1; op.stream_slot = fpn_two ? 1 : 0;
     const void* src = P->F;
     if (k == 4) {  // P7 = conv(relu(P6)): rectified copy of the P6 rows
       const int n6 = P->hl[3] * P->wl[3];

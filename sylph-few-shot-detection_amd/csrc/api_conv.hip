@@ -323,21 +323,44 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
       }
       Geom gs;
       RET(make_geom(c, ps, BM, &gs));
-      float* partial = nullptr;
       const size_t plane = (size_t)r0 * L.Cout;
-      RET(c->dalloc((void**)&partial, plane * ks * sizeof(float)));
+      // partial planes: the plan's scratch of this op's stream, grown to the largest split layer (a buffer per layer was
+      // 100-200 MB per cached batch-1 shape for scratch that is live for one launch pair); no owning plan (parity entries): own buffer
+      float** slot = nullptr;
+      float* own = nullptr;
+      if (Plan* PO = c->alloc_owner) {
+        const int si = o.stream_slot ? 1 : 0;
+        const size_t need = plane * ks * sizeof(float);
+        if (PO->splitk_bytes[si] < need) {
+          if (PO->splitk_scratch[si]) {  // ops built so far may be in flight on it: dfree drains the stream first
+            for (size_t i = 0; i < PO->allocs.size(); ++i)
+              if (PO->allocs[i] == PO->splitk_scratch[si]) { PO->allocs[i] = PO->allocs.back(); PO->allocs.pop_back(); break; }
+            PO->bytes -= (int64_t)PO->splitk_bytes[si];
+            c->dfree(PO->splitk_scratch[si]);
+            PO->splitk_scratch[si] = nullptr; PO->splitk_bytes[si] = 0;
+          }
+          RET(c->dalloc((void**)&PO->splitk_scratch[si], need));
+          PO->splitk_bytes[si] = need;
+        }
+        slot = &PO->splitk_scratch[si];
+      } else {
+        RET(c->dalloc((void**)&own, plane * ks * sizeof(float)));
+      }
       SplitSeg* ssd = nullptr;
       RET(upload(c, (void**)&ssd, ss.data(), ss.size() * sizeof(SplitSeg)));
       ConvArgs b = a;
       b.segs = gs.segs; b.tiles = gs.tiles; b.n_mtiles = gs.n_mtiles;
-      b.out = partial; b.out_ld = L.Cout; b.res = nullptr; b.res_mode = 0; b.scale = nullptr; b.shift = nullptr; b.relu_nch = 0;
+      b.out = nullptr; b.out_ld = L.Cout; b.res = nullptr; b.res_mode = 0; b.scale = nullptr; b.shift = nullptr; b.relu_nch = 0;
       b.ksplit = ks; b.split_stride = (long long)plane;
       const float *scl = L.scale, *shf = L.shift;
       const void* resp = o.res_mode == 1 ? o.res : nullptr;
       const int res_ld = o.res_ld, relu_nch = o.relu_nch, Cout = L.Cout, nseg = (int)ss.size();
       ops.push_back([=](hipStream_t s) {
         return timed_op(c, "conv_igemm_kernel", flops, s, [=](hipStream_t st) {
-          const int rc = launch_conv(dt, true, b, BM, BN, st);
+          float* partial = slot ? *slot : own;
+          ConvArgs bb = b;
+          bb.out = partial;
+          const int rc = launch_conv(dt, true, bb, BM, BN, st);
           if (rc != 0) return rc;
           return launch_splitk_finish(partial, ks, plane, Cout, Cout, ssd, nseg, max_rows, scl, shf, resp, res_ld, relu_nch, out, out_ld, st);
         });

@@ -179,6 +179,11 @@ struct Plan {
   void *x0 = nullptr, *stem_out = nullptr, *pool_out = nullptr;
   void* F = nullptr;  // pyramid [B*Ltot][256]
   void* bk_trash = nullptr;  // trash slots of the fused bottleneck kernels
+  // split-K partial planes (api_conv.hip): ONE fp32 scratch per stream slot (0 = the context's stream, 1 = its side stream), sized to
+  // the largest split layer of the plan and reused by every split layer of that stream -- stream order serialises conv -> finish ->
+  // next conv.  The ops read the pointer through the slot at launch time (the buffer may grow while the plan is still being built).
+  float* splitk_scratch[2] = {nullptr, nullptr};
+  size_t splitk_bytes[2] = {0, 0};
   // parity taps (sylph_export_stage / sylph_export_tower): where the stage outputs res2..res5 and, with debug taps on, every
   // tower layer's stored conv output and GroupNorm coefficient table live
   const void* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -274,6 +279,7 @@ struct ConvOpts {
   double flops = -1.0;     // algorithmic FLOPs of the launch when they differ from 2*M*N*K (stem padding)
   const float2* gn_coef = nullptr;  // fused GroupNorm(+ReLU) of the INPUT (conv_hpipe.hip): (a, b) per (segment, input channel)
   int gn_relu = 0;
+  int stream_slot = 0;     // 1: the op will run on the context's side stream (its split-K scratch must not be the main stream's)
 };
 
 struct BkScratch { void *t1, *t2, *sc; void** trash; };

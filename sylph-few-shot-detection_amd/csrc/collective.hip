@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/sylph_hip.h"
@@ -43,9 +44,7 @@ struct Rccl {
   std::string err;
 };
 
-Rccl* rccl() {
-  static Rccl R;
-  if (R.h || !R.err.empty()) return &R;
+void rccl_resolve(Rccl& R) {
   const char* names[] = {"librccl.so.1", "librccl.so"};
   for (const char* n : names)  // a copy that is already mapped (RTLD_NOLOAD) first
     if ((R.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
@@ -53,12 +52,13 @@ Rccl* rccl() {
     for (const char* n : names)
       if ((R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
   if (!R.h) {
-    R.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
-    return &R;
+    const char* e = dlerror();  // ONE call: dlerror() clears the message it returns
+    R.err = std::string("librccl.so not found: ") + (e ? e : "(no dlerror message)");
+    return;
   }
 #define SYM(field, name)                                                      \
   R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.h, name));            \
-  if (!R.field) { R.err = std::string("librccl: missing symbol ") + name; R.h = nullptr; return &R; }
+  if (!R.field) { R.err = std::string("librccl: missing symbol ") + name; R.h = nullptr; return; }
   SYM(get_unique_id, "ncclGetUniqueId")
   SYM(comm_init_rank, "ncclCommInitRank")
   SYM(comm_destroy, "ncclCommDestroy")
@@ -67,6 +67,13 @@ Rccl* rccl() {
   SYM(all_gather, "ncclAllGather")
   SYM(get_error_string, "ncclGetErrorString")
 #undef SYM
+}
+
+// resolved once per process, whichever thread asks first (std::call_once: concurrent first calls block until it is done)
+Rccl* rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] { rccl_resolve(R); });
   return &R;
 }
 

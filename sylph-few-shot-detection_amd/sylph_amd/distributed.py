@@ -10,7 +10,8 @@ fp32 block per rank and ONE collective (all_gather_into_tensor): no pickle, no c
 host read-back.  Row layout (ROW = 280 floats = 1120 B):
 
     [0, 256) cls_conv | 256 cls_bias | 257 acc_weight | 258 class id | 259 valid | 260 cls_weight_norm |
-    261 has_weight_norm | 262 has_acc_weight (the record carried an "acc_weight" key) | 263 pad |
+    261 has_weight_norm | 262 has_acc_weight (the record carried an "acc_weight" key) |
+    263 overflow (row 0 of a rank's block: rows that rank had to drop because they did not fit the block; 0 otherwise) |
     [264, 280) class name: 16 lanes x 3 UTF-8 bytes (longer names are cut at a character boundary, with a warning)
 
 Every rank contributes a block of the same, statically known capacity (the InferenceSampler shard size
@@ -27,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 CODE_DIM = 256
-F_BIAS, F_ACC, F_CID, F_VALID, F_WNORM, F_HAS_WNORM, F_HAS_ACC, F_NAME, NAME_FLOATS = 256, 257, 258, 259, 260, 261, 262, 264, 16
+F_BIAS, F_ACC, F_CID, F_VALID, F_WNORM, F_HAS_WNORM, F_HAS_ACC, F_OVERFLOW, F_NAME, NAME_FLOATS = 256, 257, 258, 259, 260, 261, 262, 263, 264, 16
 ROW = F_NAME + NAME_FLOATS
 NAME_BYTES = 3 * NAME_FLOATS  # 3 name bytes per fp32 lane (exact integers < 2^24)
 
@@ -106,9 +107,38 @@ def unpack_names(rows: torch.Tensor) -> List[str]:
     return [bytes(r).split(b"\0", 1)[0].decode("utf-8", "replace") for r in raw]
 
 
+class GatherOverflow(RuntimeError):
+    """Some rank held more rows than the gather block reserves.  Raised AFTER the collective, from the gathered rows, i.e. on every
+    rank with the same message."""
+
+
+def fit_block(local: torch.Tensor, capacity: int) -> torch.Tensor:
+    """Rows of one rank cut to the block's capacity.  Never raises: this runs on ONE rank right in front of a collective, and an
+    exception here would leave the other ranks blocked in it.  The number of dropped rows travels in the overflow lane of
+    the block's first row; `check_overflow` turns it into the same error on every rank once the gathered rows are on the host."""
+    n = int(local.shape[0])
+    if n <= capacity:
+        return local
+    local = local[:capacity].clone()
+    local[0, F_OVERFLOW] = float(n - capacity)
+    warnings.warn(f"{n} class-code rows on this rank do not fit the gather block of {capacity}: {n - capacity} dropped, every rank will raise")
+    return local
+
+
+def check_overflow(host_rows: torch.Tensor, capacity: Optional[int] = None):
+    """Gathered rows on the HOST -> raises GatherOverflow if any rank flagged dropped rows (identical on all ranks)."""
+    lost = host_rows[:, F_OVERFLOW]
+    if bool((lost != 0).any()):
+        cap = int(capacity) if capacity else None
+        where = [(int(i) // cap if cap else int(i), int(v)) for i, v in zip(lost.nonzero().reshape(-1).tolist(), lost[lost != 0].tolist())]
+        raise GatherOverflow("class-code gather: " + ", ".join(f"{'rank' if cap else 'row'} {r} dropped {v} row(s)" for r, v in where) +
+                             (f" that did not fit the per-rank block of {cap} rows" if cap else " that did not fit its block") +
+                             " -- the capacity passed to _gather_class_code is smaller than a rank's row count")
+
+
 def pad_block(local: torch.Tensor, capacity: int) -> torch.Tensor:
-    """(n, ROW) -> (capacity, ROW), unused rows zero (valid = 0).  n <= capacity is a host-known invariant."""
-    assert local.shape[0] <= capacity, f"{local.shape[0]} rows do not fit the gather block of {capacity}"
+    """(n, ROW) -> (capacity, ROW), unused rows zero (valid = 0); n > capacity: see fit_block."""
+    local = fit_block(local, capacity)
     if local.shape[0] == capacity:
         return local.contiguous()
     block = torch.zeros(capacity, ROW, dtype=torch.float32, device=local.device)
@@ -183,11 +213,11 @@ def gather_code_blocks(block: torch.Tensor) -> torch.Tensor:
 def gather_packed_codes(local: torch.Tensor, capacity: Optional[int] = None) -> torch.Tensor:
     """All ranks' rows in rank order, padded: (world * capacity, ROW) with valid flags (no compaction: that would need a
     host read-back; consumers select by the valid column).  capacity defaults to the local row count, which is only
-    correct when every rank holds the same number of rows."""
+    correct when every rank holds the same number of rows.  A rank with more rows than `capacity` does not raise here (the others
+    would hang in the collective): see fit_block / check_overflow."""
     cap = int(capacity) if capacity is not None else max(int(local.shape[0]), 1)
     if _c_abi_gather is not None and local.is_cuda:
-        assert local.shape[0] <= cap, f"{local.shape[0]} rows do not fit the gather block of {cap}"
-        return _c_abi_gather.gather(local, cap)  # pads inside the call (memset of the block tail on the stream)
+        return _c_abi_gather.gather(fit_block(local, cap), cap)  # pads inside the call (memset of the block tail on the stream)
     return gather_code_blocks(pad_block(local, cap))
 
 

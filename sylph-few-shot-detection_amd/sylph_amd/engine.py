@@ -56,7 +56,10 @@ def config_from_cfg(cfg) -> SylphConfig:
     sc.pre_nms_topk = int(f.PRE_NMS_TOPK_TEST)
     sc.nms_thresh = float(f.NMS_TH)
     sc.post_nms_topk = int(f.POST_NMS_TOPK_TEST)
-    sc.thresh_with_ctr = int(bool(f.THRESH_WITH_CTR))
+    # fcos_outputs.py:937 `if self.thresh_with_ctr or OWD` / :951 `if not self.thresh_with_ctr and not OWD`: with OWD the all-ones class
+    # is multiplied by the box quality BEFORE the threshold test, i.e. OWD decodes exactly like THRESH_WITH_CTR (round 5; round 4
+    # thresholded the constant 1 and kept every location as a candidate)
+    sc.thresh_with_ctr = int(bool(f.THRESH_WITH_CTR) or bool(m.PROPOSAL_GENERATOR.get("OWD", False)))
     bq = sorted(list(f.BOX_QUALITY))
     if bq == ["ctrness"]:
         sc.quality_mode = 0
@@ -302,7 +305,9 @@ class Engine:
         assert cls_conv.size(2) == 1 and cls_conv.size(3) == 1
         if self.owd:
             # `logits_pred = ones_like(logits_pred)[:, :, [0]]` after the sigmoid: one class whose probability is exactly 1 -- a zero
-            # code with bias 40 (sigmoid(40) rounds to 1.0f) through the same class-conditional conv; the towers / box heads are unchanged
+            # code with bias 40 (sigmoid(40) rounds to 1.0f) through the same class-conditional conv; the towers / box heads are unchanged.
+            # The decode then runs with thresh_with_ctr = 1 (config_from_cfg): 1.0f * quality == quality exactly, so the candidates
+            # are the locations whose quality alone clears the threshold, as in the reference (fcos_outputs.py:937)
             if getattr(self, "_owd_codes", None) is None:
                 self._owd_codes = (torch.zeros(1, 256, device=self.device), torch.full((1,), 40.0, device=self.device))
             w1, b1 = self._owd_codes

@@ -110,20 +110,17 @@ class MetaFCOSRunner:
             model.eval()
         return model
 
-    # Rows every rank reserves in the gather block when the caller passes no `capacity`: set by _do_test_meta_learning from the
-    # support loader's global item count (InferenceSampler shard size); None = agree on it with one scalar all_reduce.
-    gather_capacity: Optional[int] = None
-
     @classmethod
     def _gather_class_code(cls, sub_class_codes: List[Dict[str, Any]], reduce: bool = False, capacity: Optional[int] = None,
                            engine=None) -> List[Dict[str, Any]]:
         """meta_fcos_runner.py:381-439.  Same result as all_gather_object + rank-order flatten, but everything a code
         carries (weights, bias, accumulated weight + whether the record had one, class id, weight norm, class name) travels in
         ONE dense fp32 block per rank through ONE all_gather_into_tensor over RCCL / gloo (sylph_amd.distributed): no pickle,
-        no count exchange, no device read-back before the rows become host dicts again.  `capacity` = rows every rank reserves:
-        the argument, else `cls.gather_capacity` (what _do_test_meta_learning derives from the loader's global length -- the
-        InferenceSampler shard size ceil(n / world), known on every rank without communication); only a bare call with neither
-        falls back to one scalar all_reduce(MAX) of the local counts."""
+        no count exchange, no device read-back before the rows become host dicts again.  `capacity` = rows every rank reserves
+        (`_episode` derives it from the loader's global length -- the InferenceSampler shard size ceil(n / world), known on every
+        rank without communication); a bare call without it agrees on one with a scalar all_reduce(MAX) of the local counts.
+        A rank holding more rows than `capacity` does not raise in front of the collective (the other ranks would hang in it): the
+        overflow travels in the block and EVERY rank raises distributed.GatherOverflow afterwards."""
         world = D.get_world_size()
         if world > 1:
             import torch.distributed as dist
@@ -132,12 +129,11 @@ class MetaFCOSRunner:
                 dev = torch.device("cuda", torch.cuda.current_device())
             local = _rows_from_codes(sub_class_codes, dev)
             if capacity is None:
-                capacity = cls.gather_capacity
-            if capacity is None:
                 cap = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
                 dist.all_reduce(cap, op=dist.ReduceOp.MAX)
                 capacity = max(int(cap.item()), 1)
-            rows = D.gather_packed_codes(local, capacity)
+            rows = D.gather_packed_codes(local, capacity).cpu()
+            D.check_overflow(rows, capacity)  # same decision on every rank, after the collective
             # "acc_weight" comes back on exactly the records that carried it (explicit flag lane): nothing is inferred from values
             out_codes = _codes_from_rows(rows, keep_acc=None)
         else:

@@ -194,6 +194,72 @@ def gen_head_variants():
     np.savez_compressed(os.path.join(HERE, "g1c_head_variants.npz"), **out)
 
 
+def owd_head_state_dict():
+    """Head weights of the adversarial OWD fixture (g1d): g1's head with the centre-ness / IoU prediction convs scaled x4 and their
+    biases moved to -3 / -4.5, so that sigmoid(quality) straddles the 0.05 threshold (logit -2.944) on every level.  Shared by the generator
+    and the tests (the fixture stores a checksum, not the weights)."""
+    sd = W.head_state_dict(seed=1, num_classes=60)
+    p = "proposal_generator.fcos_head"
+    for n, b in (("ctrness", -3.0), ("iou_overlap", -4.5)):
+        sd[f"{p}.{n}.weight"] = sd[f"{p}.{n}.weight"] * 4.0
+        sd[f"{p}.{n}.bias"] = torch.full_like(sd[f"{p}.{n}.bias"], b)
+    return sd
+
+
+def gen_owd_decode():
+    """MODEL.PROPOSAL_GENERATOR.OWD decode on inputs that can SEE the order of the threshold and the quality multiply
+    (fcos_outputs.py:937 `thresh_with_ctr or OWD`, :951 `not thresh_with_ctr and not OWD`): the quality logits straddle logit(0.05) on
+    every level (the g1c `owd` case has every sigmoid(ctr) > 0.16 and cannot tell the two orders apart).
+    Stores the reference's PER-LEVEL candidate counts (forward_for_single_feature_map, pre-NMS) besides the proposals, for the three
+    BOX_QUALITY settings, with and without THRESH_WITH_CTR (which OWD makes irrelevant), and at a second threshold."""
+    from sylph.modeling.meta_fcos.fcos import MetaFCOS
+    from ref_shim import ShapeSpec
+    shapes = {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(3, 8)}
+    H, Wd, B = 128, 160, 2
+    feats = feature_pyramid(B, H, Wd, seed=11)
+    image_sizes = [(H, Wd - 7), (H - 5, Wd)]
+    codes = W.synthetic_codes(5, seed=35, scale=2.0)
+    sd = owd_head_state_dict()
+    out = {"cls_conv": codes["cls_conv"].numpy(), "cls_bias": codes["cls_bias"].numpy(), "image_sizes": np.array(image_sizes),
+           "weights_checksum": checksum(sd, "proposal_generator")}
+    with torch.no_grad():
+        cfg = make_cfg()
+        cfg.MODEL.PROPOSAL_GENERATOR.OWD = True
+        model = MetaFCOS(cfg, shapes).eval()
+        load_prefixed(model, sd, "proposal_generator")
+        logits, reg, ctr, iou, _, _ = model.fcos_head(feats, None, False, codes)
+        for l in range(5):
+            out[f"logits{l}"] = logits[l].numpy()
+            out[f"reg{l}"] = reg[l].numpy()
+            out[f"ctr{l}"] = ctr[l].numpy()
+            out[f"iou{l}"] = iou[l].numpy()
+            for name, t in (("ctr", ctr[l]), ("iou", iou[l])):
+                below = float((t.sigmoid() <= 0.05).float().mean())
+                print("owd quality", name, l, "fraction <= 0.05:", below)
+                assert 0.3 <= below <= 0.95 or t[0].numel() <= 6, (name, l, below)  # both sides of the threshold populated on every level
+        locations = model.compute_locations(feats)
+        fo = model.fcos_outputs
+        # (BOX_QUALITY, THRESH_WITH_CTR, INFERENCE_TH_TEST, NMS_TH, POST_NMS_TOPK_TEST, tag); `all`: nothing suppressed, nothing cut --
+        # the proposals ARE the candidate set (the order of threshold and multiply is visible in the final output, not only in the counts);
+        # `top300`: NMS as configured, no post-NMS cut
+        for bq, twc, thr, nms, post, tag in ((["ctrness"], False, 0.05, 0.6, 100, "ctr"), (["iou"], False, 0.05, 0.6, 100, "iou"),
+                                             (["ctrness", "iou"], False, 0.05, 0.6, 100, "ctriou"), (["ctrness"], True, 0.05, 0.6, 100, "ctr_twc"),
+                                             (["ctrness"], False, 0.02, 0.6, 100, "ctr_t20"), (["ctrness"], False, 0.05, 1.0, 1000, "ctr_all"),
+                                             (["ctrness", "iou"], False, 0.05, 1.0, 1000, "ctriou_all"), (["ctrness"], False, 0.05, 0.6, 300, "ctr_top300")):
+            fo.box_quality, fo.thresh_with_ctr, fo.pre_nms_thresh_test, fo.nms_thresh, fo.post_nms_topk_test = bq, twc, thr, nms, post
+            props = fo.predict_proposals(logits, reg, ctr, iou, locations, image_sizes, [])
+            counts = np.zeros((B, 5), dtype=np.int64)
+            for l in range(5):  # the same call predict_proposals makes per level (:800); pre_nms_thresh was set by the call above
+                per = fo.forward_for_single_feature_map(locations[l], logits[l], reg[l] * fo.strides[l], ctr[l], iou[l], image_sizes, None)
+                counts[:, l] = [len(p) for p in per]
+            out[f"{tag}_level_counts"] = counts
+            for i, p in enumerate(props):
+                out.update(inst_to_np(p, f"{tag}_img{i}"))
+            out[f"{tag}_count"] = np.array([len(p) for p in props])
+            print("owd decode", tag, counts.tolist(), [len(p) for p in props])
+    np.savez_compressed(os.path.join(HERE, "g1d_owd_decode.npz"), **out)
+
+
 def gen_codegen():
     from sylph.modeling.code_generator.code_generator import CodeGenerator
     from ref_shim import Boxes, Instances
@@ -452,7 +518,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
-    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_codegen, gen_codegen_variants, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_owd_decode, gen_codegen, gen_codegen_variants, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
         if not only or fn.__name__ in only:
             fn()
     print("done")

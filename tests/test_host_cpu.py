@@ -235,6 +235,43 @@ def test_gather_class_code_gloo_world2(golden_dir, tmp_path):
         D.order_by_class_id(rows, 6)
 
 
+def _overflow_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+        from sylph_amd.runner import MetaFCOSRunner
+        mk = lambda cid: {"support_set_target": cid, "class_name": f"c{cid}",
+                          "class_code": {"cls_conv": torch.randn(1, 256, 1, 1), "cls_bias": torch.randn(1, 1, 1, 1)}}
+        mine = [mk(0)] if rank == 0 else [mk(1), mk(2), mk(3)]  # rank 1 holds 3 rows, the block reserves 2
+        msg = "no error"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                MetaFCOSRunner._gather_class_code(mine, capacity=2)
+            except D.GatherOverflow as e:
+                msg = str(e)
+        # the process group must still be usable: nobody is stuck in the collective
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        torch.save({"msg": msg, "sum": float(t)}, f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_overflow_raises_on_every_rank_gloo_world2(tmp_path):
+    """a rank with more rows than the gather block reserves must not raise in front of the collective (the others would
+    hang in it).  The overflow travels in the block; both ranks raise the same GatherOverflow afterwards and stay in step."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ovf")
+    mp.spawn(_overflow_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}", weights_only=False) for r in (0, 1))
+    assert r0["msg"] == r1["msg"] and "rank 1 dropped 1 row(s)" in r0["msg"] and "block of 2 rows" in r0["msg"]
+    assert r0["sum"] == r1["sum"] == 3.0
+
+
 def test_acc_weight_flag_lane_survives_weight_one():
     """whether a record carries "acc_weight" travels in its own lane; a weight of exactly 1.0 keeps the key."""
     from sylph_amd.runner import _codes_from_rows, _rows_from_codes
@@ -250,7 +287,7 @@ def test_acc_weight_flag_lane_survives_weight_one():
     assert red[:, D.F_HAS_ACC].tolist() == [1.0, 0.0, 1.0] and abs(float(red[2, D.F_ACC]) - 0.5) < 1e-7
 
 
-def test_multi_seed_multi_dataset_loop_mean_and_std():
+def test_multi_seed_multi_dataset_loop_mean_and_std(tmp_path):
     """_do_test_meta_learning without explicit loaders = the reference's loop (meta_fcos_runner.py:451-672): seeds x datasets,
     seeded support loaders, pretrained codes on "base" datasets, results[f"seed{s}"], mean over seeds in results[tag], AP_avg /
     AP_std.  Host control flow only: the model is a stub that records the calls."""
@@ -309,6 +346,7 @@ def test_multi_seed_multi_dataset_loop_mean_and_std():
     cfg = r.get_default_cfg()
     cfg.DATASETS.TEST = ("coco_meta_val_novel", "coco_meta_val_base")
     cfg.TEST.REPEAT_TEST = 3
+    cfg.OUTPUT_DIR = str(tmp_path / "output")  # the support loop saves class-code files under OUTPUT_DIR/inference (not the cwd: ADVICE r4)
     cfg.MODEL.META_LEARN.EVAL_WITH_PRETRAINED_CODE = True
     cfg.MODEL.META_LEARN.USE_ALL_GTS_IN_BASE_CLASSES = False
     cfg.MODEL.META_LEARN.EPISODIC_LEARNING = True

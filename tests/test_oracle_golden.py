@@ -99,6 +99,59 @@ def test_head_variants_match_reference(g1, golden_dir, tag, share, norm, owd):
         np.testing.assert_allclose(p["pred_boxes"].numpy(), g[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
 
 
+OWD_CASES = [("ctr", ["ctrness"], False, 0.05, 0.6, 100), ("iou", ["iou"], False, 0.05, 0.6, 100), ("ctriou", ["ctrness", "iou"], False, 0.05, 0.6, 100),
+             ("ctr_twc", ["ctrness"], True, 0.05, 0.6, 100), ("ctr_t20", ["ctrness"], False, 0.02, 0.6, 100),
+             ("ctr_all", ["ctrness"], False, 0.05, 1.0, 1000), ("ctriou_all", ["ctrness", "iou"], False, 0.05, 1.0, 1000),
+             ("ctr_top300", ["ctrness"], False, 0.05, 0.6, 300)]
+
+
+def owd_head_state_dict():
+    """The head of fixture g1d (tests/golden/gen_goldens.py::owd_head_state_dict): quality convs x4, biases -3 / -4.5."""
+    sd = W.head_state_dict(seed=1, num_classes=60)
+    p = "proposal_generator.fcos_head"
+    for n, b in (("ctrness", -3.0), ("iou_overlap", -4.5)):
+        sd[f"{p}.{n}.weight"] = sd[f"{p}.{n}.weight"] * 4.0
+        sd[f"{p}.{n}.bias"] = torch.full_like(sd[f"{p}.{n}.bias"], b)
+    return sd
+
+
+@pytest.mark.parametrize("tag,bq,twc,thr,nms,post", OWD_CASES)
+def test_owd_decode_matches_reference(g1, golden_dir, tag, bq, twc, thr, nms, post):
+    """MODEL.PROPOSAL_GENERATOR.OWD on quality logits that straddle logit(0.05) on every level (g1d): the reference
+    multiplies the all-ones class by the box quality BEFORE the threshold (fcos_outputs.py:937 `thresh_with_ctr or OWD`), so its
+    candidates are the locations with quality > thresh.  Asserts the reference's PER-LEVEL candidate counts and its proposals; the
+    `*_all` cases (NMS_TH 1, no post-NMS cut) expose the whole candidate set in the output."""
+    g = _load(golden_dir, "g1d_owd_decode.npz")
+    sd = owd_head_state_dict()
+    assert abs(_checksum(sd, "proposal_generator") - float(g["weights_checksum"])) < 1e-3
+    codes = {"cls_conv": torch.from_numpy(g["cls_conv"]), "cls_bias": torch.from_numpy(g["cls_bias"])}
+    logits, regs, ctrs, ious = H.fcos_head(_feats(g1), sd, codes)
+    for l in range(5):
+        for got, name in ((regs, "reg"), (ctrs, "ctr"), (ious, "iou")):
+            np.testing.assert_allclose(got[l].numpy(), g[f"{name}{l}"], atol=TOL, rtol=TOL)
+        q = torch.from_numpy(g[f"ctr{l}"]).sigmoid()
+        assert (q <= 0.05).float().mean() >= 0.3 and (q > 0.05).any()  # the fixture can see the order of threshold and multiply
+    ref = lambda k: [torch.from_numpy(g[f"{k}{l}"]) for l in range(5)]
+    strides = (8, 16, 32, 64, 128)
+    for l in range(5):
+        h, w = g[f"ctr{l}"].shape[-2:]
+        per = D.decode_level(D.compute_locations(h, w, strides[l]), ref("logits")[l], ref("reg")[l] * strides[l], ref("ctr")[l], ref("iou")[l],
+                             thr, 1000, twc, bq, owd=True)
+        assert [p["scores"].numel() for p in per] == g[f"{tag}_level_counts"][:, l].tolist(), f"level {l} candidate count"
+    props = D.predict_proposals(ref("logits"), ref("reg"), ref("ctr"), ref("iou"), pre_nms_thresh=thr, nms_thresh=nms, post_nms_topk=post,
+                                thresh_with_ctr=twc, box_quality=bq, owd=True)
+    for i, p in enumerate(props):
+        pre = f"{tag}_img{i}"
+        assert p["scores"].numel() == int(g[f"{tag}_count"][i])
+        if tag.endswith("_all"):
+            assert p["scores"].numel() == int(g[f"{tag}_level_counts"][i].sum())
+        np.testing.assert_array_equal(p["pred_classes"].numpy(), g[f"{pre}_pred_classes"])
+        np.testing.assert_array_equal(p["fpn_levels"].numpy(), g[f"{pre}_fpn_levels"])
+        np.testing.assert_array_equal(p["locations"].numpy(), g[f"{pre}_locations"])
+        np.testing.assert_allclose(p["scores"].numpy(), g[f"{pre}_scores"], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(p["pred_boxes"].numpy(), g[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
+
+
 VARIANTS = [("iou", ["iou"], False), ("ctriou", ["ctrness", "iou"], False), ("ctr_twc", ["ctrness"], True),
             ("iou_twc", ["iou"], True), ("ctriou_twc", ["ctrness", "iou"], True)]
 
