@@ -51,15 +51,19 @@ class _Collect:
         return {"n": len(self.out)}
 
 
-def test_runner_episode_matches_oracle(model, sd):
+@pytest.mark.parametrize("ways,shots,nq,bs", [(3, 2, 4, 2), (5, 1, 2, 1)], ids=["3way2shot_4q", "C1_5way1shot_2q"])
+def test_runner_episode_matches_oracle(model, sd, ways, shots, nq, bs):
+    """One episode through MetaFCOSRunner with the COCO Meta-FCOS-finetune.yaml against the fp32 oracle.  `C1_5way1shot_2q` is
+    BASELINE.json configs[0] to the letter: R-50-FPN, 5-way 1-shot, 2 query images, query batch 1 (the reference's loop B,
+    meta_learn_evaluation.py:421-426)."""
     from oracle import codegen as CG, episode as E
     from sylph_amd.data import SyntheticQueryLoader, SyntheticSupportSetLoader
     runner, cfg = _cfg()
-    sup = SyntheticSupportSetLoader(3, 2, 128, 160, seed=3)
-    qry = SyntheticQueryLoader(4, 120, 152, batch_size=2, seed=4)
+    sup = SyntheticSupportSetLoader(ways, shots, 128, 160, seed=3)
+    qry = SyntheticQueryLoader(nq, 120, 152, batch_size=bs, seed=4)
     ev = _Collect()
-    res, codes = runner._do_test_meta_learning(cfg, model, sup, qry, ev, num_classes=3)
-    assert res == {"n": 4} and codes["cls_conv"].shape == (3, 256, 1, 1) and codes["cls_bias"].shape == (3,)
+    res, codes = runner._do_test_meta_learning(cfg, model, sup, qry, ev, num_classes=ways)
+    assert res == {"n": nq} and codes["cls_conv"].shape == (ways, 256, 1, 1) and codes["cls_bias"].shape == (ways,)
     # oracle: same support items -> codes
     recs = []
     for item in sup:

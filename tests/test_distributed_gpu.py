@@ -213,3 +213,83 @@ def test_bench_multi_rank_control_flow_on_one_device(tmp_path):
         assert out["episode_setup"]["code_gather_is_collective"] is True
         assert cn["valid"].tolist() == [1.0] * 5
         assert torch.equal(cn["codes"], c1["codes"]), f"class codes of the {n}-rank episode differ from the single-rank episode"
+
+
+_EPISODE_GATHER_SCRIPT = r"""
+import os, sys
+root = %(root)r
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "sylph-few-shot-detection_amd"))
+import torch, torch.distributed as dist
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+torch.cuda.set_device(0)                      # every rank on the ONE GPU of the test box
+if world > 1:
+    dist.init_process_group("gloo")
+from sylph_amd import distributed as D, synthetic as W
+from sylph_amd.data import SyntheticSupportSetLoader
+from sylph_amd.evaluation import format_class_codes_shared, inference_normalization, inference_on_support_set_dataset
+from sylph_amd.runner import MetaFCOSRunner, MetaFCOSROIEncoderRunner, create_cfg
+kind, ways, shots, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+if kind == "c4":     # BASELINE configs[3]: R-101-FPN LVISv1 Meta-FCOS, 866-way 5-shot, 8 ranks
+    runner = MetaFCOSRunner()
+    cfg = create_cfg(runner.get_default_cfg(), "sylph://LVISv1-Detection/Meta-FCOS/Meta-FCOS-finetune.yaml",
+                     ["MODEL.RESNETS.DEPTH", 101, "MODEL.META_LEARN.EVAL_SHOT", shots])
+    sd = W.synthetic_state_dict(0, depth=101, num_classes=866)
+else:                # BASELINE configs[4]: ROIEncoder code generator, LVIS rare 337-way 5-shot, 4 ranks
+    runner = MetaFCOSROIEncoderRunner()
+    cfg = create_cfg(runner.get_default_cfg(), "sylph://LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml",
+                     ["MODEL.META_LEARN.EVAL_SHOT", shots])
+    sd = {}
+    sd.update(W.backbone_state_dict(0, depth=50)); sd.update(W.head_state_dict(1, num_classes=60)); sd.update(W.roi_encoder_state_dict(seed=4))
+model = runner.build_model(cfg, dtype="f32")
+model.load_state_dict(sd)
+model.eval()
+sup = SyntheticSupportSetLoader(ways, shots, 64, 96, seed=13)      # sharded in contiguous blocks (InferenceSampler rule)
+sub = inference_on_support_set_dataset(model, sup, output_dir=None)
+cap = D.shard_capacity(ways)
+assert len(sub) == len(sup) <= cap
+codes = runner._gather_class_code(sub, capacity=cap)                # THE collective: [cap][280] block per rank
+assert len(codes) == ways and [int(c["support_set_target"]) for c in codes] == list(range(ways))
+assert [c["class_name"] for c in codes] == [f"class_{i}" for i in range(ways)]          # names travel in the block
+assert not any("acc_weight" in c["class_code"] for c in codes)                        # HAS_ACC lane: few-shot records carry none
+if kind == "c4":
+    codes = inference_normalization(model, codes)
+fm = format_class_codes_shared(codes, device="cpu")
+if rank == 0:
+    torch.save({"cls_conv": fm["cls_conv"].cpu(), "cls_bias": fm["cls_bias"].cpu(), "cap": cap, "world": world}, out)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+print("EPISODE_GATHER_OK")
+"""
+
+
+@pytest.mark.parametrize("kind,ways,shots,ranks", [("c4", 866, 5, 8), ("c5", 337, 5, 4)], ids=["C4_866way_8ranks", "C5_337way_4ranks"])
+def test_runner_code_gather_at_real_sizes_on_one_device(tmp_path, kind, ways, shots, ranks):
+    """the 8-rank half of BASELINE configs[3] (R-101 LVIS yaml, 866 classes x 5 shots -> 109-row blocks, the last
+    rank's block partly empty) and the 4-rank half of configs[4] (ROIEncoder yaml, 337 classes -> 85-row blocks) through
+    MetaFCOSRunner: support loop on every rank's class shard -> ONE all_gather_into_tensor of [capacity][280] blocks (names, HAS_ACC
+    lane) -> normalise -> format.  All ranks share the test box's one GPU over gloo; the formatted class codes must be bit-identical
+    to the single-rank episode (fp32: a class's arithmetic does not depend on the rank or batch it was computed in)."""
+    import socket
+    script = str(tmp_path / "episode_gather.py")
+    with open(script, "w") as f:
+        f.write(_EPISODE_GATHER_SCRIPT % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for n in (1, ranks):
+        out = str(tmp_path / f"codes_w{n}.pt")
+        if n == 1:
+            cmd = [sys.executable, script, kind, str(ways), str(shots), out]
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), script, kind, str(ways), str(shots), out]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0 and "EPISODE_GATHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[n] = torch.load(out)
+    one, many = outs[1], outs[ranks]
+    assert many["world"] == ranks and many["cap"] == -(-ways // ranks) and many["cap"] * ranks >= ways
+    assert tuple(many["cls_conv"].shape) == (ways, 256, 1, 1) and tuple(many["cls_bias"].shape) == (ways,)
+    assert torch.isfinite(many["cls_conv"]).all() and float(many["cls_conv"].abs().sum()) > 0
+    assert torch.equal(many["cls_conv"], one["cls_conv"]) and torch.equal(many["cls_bias"], one["cls_bias"])

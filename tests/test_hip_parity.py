@@ -214,11 +214,19 @@ def test_owd_decode_matches_reference_golden(g1, golden_dir, tag, bq, twc, thr, 
         if tag.endswith("_all") and ref["scores"].numel() == n_ref_raw:  # nothing suppressed, cut or emptied by the clip: candidates per level
             got_counts = np.bincount(d["fpn_levels"].cpu().numpy(), minlength=5)
             np.testing.assert_array_equal(got_counts, g[f"{tag}_level_counts"][i])
-        np.testing.assert_array_equal(d["pred_classes"].cpu().numpy(), ref["pred_classes"].numpy())
-        np.testing.assert_array_equal(d["fpn_levels"].cpu().numpy(), ref["fpn_levels"].numpy())
-        np.testing.assert_array_equal(d["locations"].cpu().numpy(), ref["locations"].numpy())
-        np.testing.assert_allclose(d["scores"].cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
-        np.testing.assert_allclose(d["pred_boxes"].cpu().numpy(), ref["pred_boxes"].numpy(), atol=1e-3, rtol=1e-4)
+        order_g = order_r = slice(None)
+        if via == "head":
+            # the HIP head's quality logits differ from the reference's by ~1e-6: near-tied scores may swap places in the score-sorted
+            # output, so the SET of (level, location, class) detections is compared (the imported-head variant compares the order too)
+            key = lambda x: np.lexsort((x["pred_classes"].cpu().numpy(), x["locations"].cpu().numpy()[:, 0], x["locations"].cpu().numpy()[:, 1],
+                                        x["fpn_levels"].cpu().numpy()))
+            order_g, order_r = key(d), key(ref)
+        pick = lambda x, k, o: x[k].cpu().numpy()[o]
+        np.testing.assert_array_equal(pick(d, "pred_classes", order_g), pick(ref, "pred_classes", order_r))
+        np.testing.assert_array_equal(pick(d, "fpn_levels", order_g), pick(ref, "fpn_levels", order_r))
+        np.testing.assert_array_equal(pick(d, "locations", order_g), pick(ref, "locations", order_r))
+        np.testing.assert_allclose(pick(d, "scores", order_g), pick(ref, "scores", order_r), atol=1e-3)
+        np.testing.assert_allclose(pick(d, "pred_boxes", order_g), pick(ref, "pred_boxes", order_r), atol=1e-3, rtol=1e-4)
 
 
 @pytest.mark.parametrize("tag,thr", [("n1_t50", 0.05), ("n5_t50", 0.05), ("n20_t50", 0.05), ("n20_t11", 0.011)])
