@@ -329,7 +329,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
       float** slot = nullptr;
       float* own = nullptr;
       if (Plan* PO = c->alloc_owner) {
-        const int si = o.stream_slot ? 1 : 0;
+        const int si = (o.stream_slot || c->build_slot) ? 1 : 0;
         const size_t need = plane * ks * sizeof(float);
         if (PO->splitk_bytes[si] < need) {
           if (PO->splitk_scratch[si]) {  // ops built so far may be in flight on it: dfree drains the stream first

@@ -42,6 +42,7 @@ int ensure_gn_ws(sylph_ctx* c, Plan* P, int nseg, int max_rows) {
 int build_head(sylph_ctx* c, Plan* P) {
   if (P->head_built) return 0;
   if (!c->has_head) return fail("FCOS head weights were not loaded");
+  c->build_slot = 0;  // (an earlier build that failed half-way may have left it set)
   RET(ensure_pyramid(c, P));
   const size_t e = c->esz();
   const size_t rows = (size_t)P->B * P->Ltot;
@@ -169,6 +170,9 @@ int build_head(sylph_ctx* c, Plan* P) {
     P->cls_apply = cls_apply;
     box_defer = defer && c->pred_taps && !c->box_tower.empty();
     side_from = ops.size();
+    // from here to the join the ops run on the side stream: a split-K conv among them (towers without GroupNorm, the prediction conv)
+    // must take the side stream's partial-plane scratch, not the one the cls tower is using at the same time
+    c->build_slot = two_streams ? 1 : 0;
     RET(tower(1, c->box_tower, c->box_gn, P->tC, P->tD, &box_feat, box_defer ? &box_coef : nullptr, &box_apply));
   }
   P->cls_ld = feat_ld;
@@ -193,6 +197,7 @@ int build_head(sylph_ctx* c, Plan* P) {
     ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
     RET(add_conv(c, ops, c->pred, box_feat, feat_ld, P->pred, 8, segs, op));
   }
+  c->build_slot = 0;
   if (two_streams) {
     for (size_t k = side_from; k < ops.size(); ++k) {
       const OpFn inner = ops[k];

@@ -140,6 +140,7 @@ struct sylph_ctx {
   // small batches: the two FCOS towers of a head pass run on two streams (fork / join events around the bbox tower, api_head.hip)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int build_slot = 0;  // plan building: 1 while the ops being added will run on the side stream (split-K scratch slot, api_conv.hip)
   // optional per-launch timing of the MFMA conv kernel (bench.py roofline): HIP events on the launch stream
   bool prof = false;
   struct ProfRec { hipEvent_t a, b; double flops; const char* kern; };

@@ -87,6 +87,7 @@ int sylph_bottleneck(sylph_ctx* c, const float* x, int B, int Cin, int H, int W,
   if (!has_sc && (Cin != cout || stride != 1)) return fail("sylph_bottleneck: an identity block needs Cin == cout and stride 1");
   sylph_ctx tmp;  // scratch allocations freed on return
   tmp.device = c->device; tmp.dt = c->dt; tmp.stream = c->stream; tmp.zeros = c->zeros; tmp.cfg = c->cfg;
+  tmp.prof = c->prof;  // per-launch HIP-event timing (tools/bench_bottleneck.py): the records move to the caller's context below
   struct Guard { sylph_ctx* t; hipStream_t s; ~Guard() { (void)hipStreamSynchronize(s); for (void* p : t->allocs) (void)hipFree(p); } } guard{&tmp, c->stream};
   sylph_ctx::Block blk;
   const int cins[4] = {Cin, mid, mid, Cin}, couts[4] = {mid, mid, cout, cout}, ks[4] = {1, 3, 1, 1};
@@ -119,6 +120,8 @@ int sylph_bottleneck(sylph_ctx* c, const float* x, int B, int Cin, int H, int W,
   BkScratch scr{t1, t2, sc, &trash};
   RET(add_bottleneck(&tmp, ops, blk, B, xin, Cin, H, W, stride, mid, cout, yout, scr));
   RET(run_ops(c, ops, "bottleneck"));
+  for (auto& r : tmp.prof_recs) c->prof_recs.push_back(r);
+  tmp.prof_recs.clear();
   for (int b = 0; b < B; ++b)
     KCHK(launch_export_nchw(c->dt, yout, y + (size_t)b * cout * Ho * Wo, cout, Ho * Wo, b * Ho * Wo, cout, c->stream), "export");
   return 0;
