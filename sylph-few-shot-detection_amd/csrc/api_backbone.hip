@@ -78,14 +78,10 @@ int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block&
     std::vector<SegDesc> sg = image_segs(B, Hin, Win, Hin, Win);
     std::vector<BkTile> bt;
     int ph, pw;
-    // SYLPH_BK_SMALL=1 (A/B knob): identity block on 64-position patches (8 x 8 on the 200 x 336 map) whose 128-row halo is
-    // double-buffered and prefetched a whole tile ahead (bottleneck.hip <2, 1, 2, true>).  Measured 1.56 ms vs 1.31 ms per launch at
-    // B = 64: the halo round trip is hidden, but 2.2 x as many tiles pay the per-tile fixed costs (five barriers, three pipeline
-    // fills / MFMA drains, descriptor and address set-up: ~2.3 us per tile) -- the <= 128-position geometry stays the default.
-    static const int bk_small_on = SYLPH_AB_ENV("SYLPH_BK_SMALL", 0);
-    const int bk_small = fuse_id && bk_small_on;
-    if (bk_small) pick_patch(Hin, Win, 64, 128, 2, &ph, &pw);
-    else pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
+    // (A 64-position variant with a double-buffered halo was measured in round 3: 1.56 vs 1.31 ms per launch -- 2.2 x as many tiles pay
+    // the per-tile fixed costs; it left the tree in round 5, see bottleneck.hip.)
+    const int bk_small = 0;
+    pick_patch(Hin, Win, 128, 184, 2, &ph, &pw);
     for (size_t si2 = 0; si2 < sg.size(); ++si2)
       for (int yy = 0; yy < Hin; yy += ph)
         for (int xx = 0; xx < Win; xx += pw)

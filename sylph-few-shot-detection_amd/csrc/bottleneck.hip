@@ -21,7 +21,12 @@
 //     into registers), all waves issue the NEXT tile's halo: 96 KiB per CU in flight during conv2 / conv3 -- enough to cover
 //     the HBM latency at the CU's bandwidth share, which the two-block design could not.
 //   * conv3 epilogue in registers (D^T MFMA layout: a lane owns 4 consecutive channels of a position): bn3 + residual + ReLU ->
-//     bf16, 8-byte stores; a wave writes complete 128-byte lines of a position within eight consecutive stores.
+//     bf16 -> a wave-private 32 x 64-channel LDS tile -> read back row-major -> 16-byte stores, 8 lanes per 128-byte line (round 5).
+//     Rounds 2-4 stored the fragments directly (8 bytes per lane: every instruction is 32 write requests of 16 bytes, and a CU
+//     retires about one request per cycle): 1.29 -> 1.09 ms per launch at B = 64, profiles/r5_bottleneck_ablation.txt.
+//   * Round-5 experiment (git history: "experiment: x halo as a ring of 64-channel chunks"): conv1 walking K in four 24-KiB chunks
+//     through five ring slots, so that the next patch's halo is in flight during conv1 too.  Parity-clean; it hides 86 us more of
+//     the loads per launch and costs 140 us of compute (seven barriers per patch instead of four, four pipeline fills in conv1).
 //
 // P1 recomputes conv1 on the (ph+2) x (pw+2) halo (+40 % of its flops); halo positions outside the image are forced to 0
 // (they are conv2's zero padding).  P2 reads shifted rows of the t1 halo exactly like conv_igemm.hip's HALO mode.
@@ -83,12 +88,9 @@ constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 
 // NR1 / NR2 / NR3: 32-row MFMA tiles a wave processes in P1 (halo rows) / P2 / P3 (patch positions); XR = NR1 * 64 halo rows.
 //   <3, 2, 4, false>: patches of <= 128 positions, ONE 96-KiB halo buffer, the next halo issued after conv1 (round 2);
-//   <2, 1, 2, true>:  patches of <= 64 positions (8 x 8), TWO 64-KiB halo buffers: the next patch's halo is issued at the TOP of
-//                     a tile, a whole tile ahead, and lands under conv1 / conv2 / conv3 of the current one (round-3 experiment: the
-//                     identity block is limited by the halo round trip, 0.80 ms of compute in 1.29 ms).  MFMA work per position is
-//                     the same (P1 recomputes 128 / 64 halo rows per position instead of 192 / 120, P2 / P3 run full 64 / 64 tiles
-//                     instead of 120 / 128), but 2.2 x as many tiles pay the per-tile fixed costs: measured 1.56 ms vs 1.31 ms per
-//                     launch at B = 64.  Parity-clean, kept behind SYLPH_BK_SMALL=1 in -DSYLPH_ABLATE builds for A/B runs; NOT the default.
+//   <2, 1, 2, true>:  (round-3 experiment, no longer instantiated: patches of <= 64 positions, TWO 64-KiB halo buffers, the next
+//                     patch's halo issued a whole tile ahead.  The halo round trip was hidden, but 2.2 x as many tiles paid the
+//                     per-tile fixed costs: 1.56 ms vs 1.31 ms per launch at B = 64.  Its LDS no longer fits beside the store staging.)
 template <int NR1, int NR2, int NR3, bool DB>
 __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckArgs a) {
   constexpr int XR = NR1 * 64;                     // halo rows of a buffer
@@ -477,393 +479,6 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Identity block, x halo as a RING of 64-channel chunks (round 5).  bottleneck64_kernel<3, 2, 4, false> can only issue the next
-// patch's 96-KiB halo once conv1 has consumed the current one (one buffer is all that fits), so HBM idles during conv1 + the residual
-// copy and the block idles while the rest of the halo lands: 9.1 us per patch at B = 64 for 5.7 us of compute and ~6.1 us of HBM
-// time (3.5 TB/s).  Here conv1 walks K in four 64-channel chunks [192 rows][128 B] (24 KiB, the layout of
-// bottleneck64p_kernel's halo) that live in FIVE ring slots: chunk n = 4 * patch + c sits in slot n mod 5 and chunk n + 5 is issued
-// as soon as every wave has finished with chunk n, one barrier later.  120 KiB of halo are in flight or resident at any time, the
-// loads never stop, and conv1 of patch t + 1 starts on chunks that landed under conv2 / conv3 of patch t.
-//   * The residual of wave w's conv3 outputs (channels 64 w .. 64 w + 63) is exactly the centre of chunk w: the wave copies it to
-//     registers in phase w, before the chunk's slot is released.
-//   * vmcnt bookkeeping (in-order retirement, fixed issue counts -- patches past the end re-fetch the current one, every lane always
-//     issues its 32 stores): per patch a wave issues 3 x 6 LDS-DMA loads (after the barriers B1 .. B3), 32 stores and 6 more loads
-//     (chunk 0 of the patch after the next, at the end of the patch).  At Bc (c = 1 .. 3) the chunk needed was issued at Bc of the
-//     previous patch: 18 loads + 32 stores issued since = vmcnt(50); at B0 the chunk was issued at the end of the patch before the
-//     previous one (or last in the prologue): 18 loads + 32 stores + 6 loads since = vmcnt(56).
-//   * Seven barriers per patch instead of four; t1 / t2, conv2, conv3 and the epilogue are those of the one-buffer kernel.
-namespace {
-constexpr int RC_BYTES = XROWS * 128;                       // one chunk: 24 576
-constexpr int RNSLOT = 5;
-constexpr int RT1_OFF = RNSLOT * RC_BYTES;                  // t1 halo [192][64 ch] (pitch TP); t2 aliases it
-constexpr int RBN_OFF = RT1_OFF + XROWS * TP;
-constexpr int RLDS_BYTES = RBN_OFF + (4 * MID + 2 * C) * 4;  // 153 600
-}  // namespace
-
-__global__ __launch_bounds__(256, 1) void bottleneck64r_kernel(const BottleneckArgs a) {
-  constexpr int NR1 = 3, NR2 = 2, NR3 = 4;
-  typedef bf16_t T;
-  typedef int i32x8 __attribute__((ext_vector_type(8)));
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
-  T* __restrict__ y = reinterpret_cast<T*>(a.y);
-  char* const trash = reinterpret_cast<char*>(a.trash) + ((size_t)blockIdx.x * 256 + tid) * 128;
-  char* const t1 = smem + RT1_OFF;
-  float* const bn = reinterpret_cast<float*>(smem + RBN_OFF);
-  const unsigned smem_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem;
-
-  // ---- weights -> registers (as bottleneck64_kernel) ---------------------------------------------------------------------------
-  const int ct1 = wave >> 1;
-  bf16x8 W1f[16], W2f[36], W3f[2][4];
-  {
-    const T* w1p = a.w1 + ((ct1 * 32 + l31) * C + lh * 8);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) W1f[ks] = *reinterpret_cast<const bf16x8*>(w1p + ks * 16);
-    const T* w2p = a.w2 + ((ct1 * 32 + l31) * 9 * MID + lh * 8);
-#pragma unroll
-    for (int k = 0; k < 36; ++k) W2f[k] = *reinterpret_cast<const bf16x8*>(w2p + k * 16);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const T* w3p = a.w3 + (((2 * wave + j) * 32 + l31) * MID + lh * 8);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) W3f[j][ks] = *reinterpret_cast<const bf16x8*>(w3p + ks * 16);
-    }
-  }
-  for (int i = tid; i < 4 * MID + 2 * C; i += 256) {
-    const float* src = i < MID ? a.s1 + i : i < 2 * MID ? a.b1 + (i - MID) : i < 3 * MID ? a.s2 + (i - 2 * MID)
-                     : i < 4 * MID ? a.b2 + (i - 3 * MID) : i < 4 * MID + C ? a.s3 + (i - 4 * MID) : a.b3 + (i - 4 * MID - C);
-    bn[i] = *src;
-  }
-  const float *s1 = bn, *s2 = bn + 2 * MID;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  const int G = gridDim.x, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, gx = (G + 7) >> 3;
-  const int chunk = (a.n_tiles + 7) >> 3;
-  auto tile_of = [&](int it) { const int q = it * gx + jb; return __builtin_amdgcn_readfirstlane(q < chunk ? xcd * chunk + q : a.n_tiles); };
-  auto load_tile = [&](int t) {
-    i32x8 v;
-    const BkTile* p = a.bk + t;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
-    return v;
-  };
-  // Halo rows of patch d -> byte offsets into x, ONE per LDS-DMA round (6 rounds of 32 rows x 128 B; the same six offsets serve the
-  // four chunks of the patch: chunk c adds 128 c).  Slot s of LDS row h holds the 16-byte piece
-  // s ^ ((h >> 1) & 7) -- a per-lane constant (the rounds are 32 rows apart), folded into the offsets.  Rows past the halo re-read
-  // its last row (a cache hit, never used); halo rows outside the image come from a clamped address (never used: P1 masks t1 there,
-  // the residual is read at stored positions).
-  const int xr = tid >> 3, xs = tid & 7;
-  const unsigned swz16 = (unsigned)((xs ^ ((xr >> 1) & 7)) << 4);
-  auto halo_offsets = [&](const i32x8 d, unsigned (&go)[6]) {
-    const int row0 = d[0], H = d[1], W = d[2], oy0 = d[3] >> 16, ox0 = d[3] & 0xffff, HW2 = d[5] + 2, HR = (d[4] + 2) * HW2;
-    const unsigned inv_hw2 = (unsigned)d[7];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int h = min(r * 32 + xr, HR - 1);
-      const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
-      const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
-      go[r] = ((unsigned)(row0 + iy * W + ix) << 9) + swz16;
-    }
-  };
-  // chunk c of the patch whose offsets are `go` -> ring slot sl: ALWAYS six loads per wave
-  auto issue_chunk = [&](const unsigned (&go)[6], int c, int sl) {
-    char* const dst = smem + sl * RC_BYTES + wave * 1024;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-#ifndef BK_NOX
-      // (no immediate offset: the instruction offset of an LDS-DMA load moves the LDS address as well)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + (go[r] + (unsigned)(c << 7))), (lds_ptr_t)(dst + r * 4096), 16, 0, 0);
-#else
-      if (go[r] == 0xffffffffu) *reinterpret_cast<volatile unsigned*>(dst + r * 4096) = go[r];  // keeps the address math alive
-#endif
-    }
-  };
-  auto relu_pk = [](unsigned u, unsigned keep) {
-    const s16x2 z = {0, 0};
-    const s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, u), z);
-    return __builtin_bit_cast(unsigned, r) & keep;
-  };
-  auto pack2 = [](float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v;
-    v[0] = (bf16_t)lo;
-    v[1] = (bf16_t)hi;
-    return __builtin_bit_cast(unsigned, v);
-  };
-
-  int t = tile_of(0), tn1 = tile_of(1);
-  if (t >= a.n_tiles) return;
-  i32x8 td = load_tile(t);
-  i32x8 td1 = load_tile(tn1 < a.n_tiles ? tn1 : t);  // past the end: the current patch again (fixed issue counts, valid addresses)
-  unsigned goff1[6];  // halo offsets of the NEXT patch (its chunks 1 .. 3 are issued during this one)
-  {
-    unsigned g0[6];
-    halo_offsets(td, g0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) issue_chunk(g0, c, c);
-  }
-  halo_offsets(td1, goff1);
-  issue_chunk(goff1, 0, 4);
-  int s0 = 0;  // ring slot of chunk 0 of the current patch
-  const int rb1 = (wave & 1) * NR1, rb2 = (wave & 1) * NR2;
-  // per-lane constants of the P1 fragment reads: byte offset of k-step ks inside a chunk row, swizzled ((l31 >> 1) & 7 is the row key:
-  // the row tiles are multiples of 32 rows apart)
-  unsigned koff[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)((ks * 32) ^ ((((l31 >> 1) & 7) ^ lh) << 4));
-
-  for (int it = 0; t < a.n_tiles; ++it) {
-    const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
-    const int PW = td[5], HW2 = PW + 2, HR = (td[4] + 2) * HW2, NPOS = td[4] * PW;
-    const unsigned inv_pw = (unsigned)td[6], inv_hw2 = (unsigned)td[7];
-    const int tn2 = tile_of(it + 2);
-    const i32x8 td2 = load_tile(tn2 < a.n_tiles ? tn2 : t);
-
-    // output pointers and the residual's place in chunk `wave` of this lane's conv3 outputs (positions rt * 32 + l31)
-    char* yptr[NR3];
-    unsigned roff[NR3];
-    int lzr;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lzr));
-#pragma unroll
-    for (int rt = 0; rt < NR3; ++rt) {
-      const int m = rt * 32 + l31 + lzr;
-      const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
-      const bool pv = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
-      yptr[rt] = pv ? reinterpret_cast<char*>(y) + ((size_t)(unsigned)(row0 + (oy0 + my) * IW + ox0 + mx) * (C * 2) + 128 * wave + 8 * lh) : trash;
-      const int hc = min((my + 1) * HW2 + mx + 1, XROWS - 1);
-      roff[rt] = (unsigned)(hc * 128 + (((hc >> 1) & 7) << 4) + 8 * lh);  // piece p of this row sits at roff ^ (p << 4)
-    }
-    u32x2 res[NR3 * 8];
-
-    // ===== P1: t1 = relu(bn1(x_halo . W1^T)) over the four chunks of the ring ====================================================
-    f32x16 acc1[NR1];
-    {
-      int lz1;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(lz1));
-      const unsigned arow = (unsigned)((rb1 * 32 + l31 + lz1) * 128);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // chunk c of this patch has landed (all of it: every wave waits for its own six loads, then the barrier)
-        if (c == 0) {
-          if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(50)" ::: "memory");
-        }
-        BK_BAR();  // ... and every wave is done with chunk c - 1 (its reads were waited for) and, at c = 0, with t1 / t2 of the previous patch
-        int sl = s0 + c;
-        sl = sl >= RNSLOT ? sl - RNSLOT : sl;
-        if (c > 0) {  // the slot of chunk c - 1 takes chunk c of the NEXT patch
-          int sp = s0 + c - 1;
-          sp = sp >= RNSLOT ? sp - RNSLOT : sp;
-          issue_chunk(goff1, c, sp);
-        }
-        const unsigned cb = smem_lds + (unsigned)(sl * RC_BYTES) + arow;
-        bf16x8 af[4][NR1];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const unsigned ad = cb + koff[ks];
-          asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks][0]) : "v"(ad));
-          asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(af[ks][1]) : "v"(ad));
-          asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(af[ks][2]) : "v"(ad));
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          // fragment reads issued after those of k-step ks: 3 per later k-step (the LGKM counter has 4 bits: at most 15 outstanding)
-          if (ks == 0) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]));
-          else if (ks == 1) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]));
-          else if (ks == 2) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(af[2][0]), "+v"(af[2][1]), "+v"(af[2][2]));
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[3][0]), "+v"(af[3][1]), "+v"(af[3][2]));
-#pragma unroll
-          for (int i = 0; i < NR1; ++i) {
-            if (c == 0 && ks == 0) BK_MFMA0(acc1[i], W1f[0], af[0][i]);
-            else BK_MFMA(acc1[i], W1f[c * 4 + ks], af[ks][i]);
-          }
-        }
-        if (wave == c) {  // residual of this wave's conv3 outputs: the centre rows of chunk `wave`, 32 x 8 bytes per lane, read under
-                          // the chunk's MFMAs; retired by the lgkmcnt(0) of the next barrier, before the slot is released
-          const unsigned rbase = smem_lds + (unsigned)(sl * RC_BYTES);
-#pragma unroll
-          for (int rt = 0; rt < NR3; ++rt)
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-              const unsigned ad = rbase + (roff[rt] ^ (unsigned)(p << 4));
-              asm volatile("ds_read_b64 %0, %1" : "=v"(res[rt * 8 + p]) : "v"(ad));
-            }
-        }
-      }
-      // the residual values are complete (their reads are older than nothing still pending after this wait)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]),
-                     "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]), "+v"(res[15]));
-      asm volatile(""
-                   : "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]), "+v"(res[20]), "+v"(res[21]), "+v"(res[22]), "+v"(res[23]),
-                     "+v"(res[24]), "+v"(res[25]), "+v"(res[26]), "+v"(res[27]), "+v"(res[28]), "+v"(res[29]), "+v"(res[30]), "+v"(res[31]));
-      BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
-      const float* sp = s1 + ct1 * 32 + 4 * lh;  // b1 = s1 + 64
-#pragma unroll
-      for (int i = 0; i < NR1; ++i) {
-        const int h = (rb1 + i) * 32 + l31 + lz1;
-        const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
-        const bool in1 = h < HR && (unsigned)(oy0 - 1 + hy) < (unsigned)IH && (unsigned)(ox0 - 1 + hx) < (unsigned)IW;
-        const unsigned keep = in1 ? 0xffffffffu : 0u;
-        char* wp = t1 + h * TP + ct1 * 64 + 8 * lh;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + MID + 8 * gq);
-          u32x2 o;
-          o[0] = relu_pk(pack2(acc1[i][4 * gq] * sv[0] + bv[0], acc1[i][4 * gq + 1] * sv[1] + bv[1]), keep);
-          o[1] = relu_pk(pack2(acc1[i][4 * gq + 2] * sv[2] + bv[2], acc1[i][4 * gq + 3] * sv[3] + bv[3]), keep);
-          *reinterpret_cast<u32x2*>(wp + gq * 16) = o;
-        }
-      }
-    }
-    BK_BAR();  // B4: t1 complete; every wave is done with chunk 3 (its slot is refilled at the end of the patch)
-
-    // ===== P2: t2 = relu(bn2(conv3x3(t1))) (as bottleneck64_kernel) ==============================================================
-    {
-      int lz2;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(lz2));
-      const int l31b = l31 + lz2;
-      f32x16 acc2[NR2];
-      const char* hrow[NR2];
-#pragma unroll
-      for (int i = 0; i < NR2; ++i) {
-        const int m = (rb2 + i) * 32 + l31b;
-        const int my = (int)(((unsigned)m * inv_pw) >> 16);
-        hrow[i] = t1 + (my * HW2 + (m - my * PW)) * TP + 16 * lh;
-      }
-      constexpr int D2 = 4;
-      bf16x8 af[D2][NR2];
-      auto p2_read = [&](int k) {
-        const int tap = k >> 2, ks = k & 3, kh = tap / 3, kw = tap - 3 * kh;
-#pragma unroll
-        for (int i = 0; i < NR2; ++i) {
-          const unsigned ad = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(hrow[i] + (kh * HW2 + kw) * TP);
-          if (ks == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(af[k % D2][i]) : "v"(ad));
-          else if (ks == 1) asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(af[k % D2][i]) : "v"(ad));
-          else if (ks == 2) asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(af[k % D2][i]) : "v"(ad));
-          else asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(af[k % D2][i]) : "v"(ad));
-        }
-      };
-#pragma unroll
-      for (int k = 0; k < D2 - 1; ++k) p2_read(k);
-#pragma unroll
-      for (int k = 0; k < 36; ++k) {
-        if (k + D2 - 1 < 36) p2_read(k + D2 - 1);
-        const int ahead = (k + D2 - 1 < 36 ? D2 - 1 : 35 - k) * NR2;
-        if (ahead == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-        else if (ahead == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-        else if (ahead == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[k % D2][0]), "+v"(af[k % D2][1]));
-#pragma unroll
-        for (int i = 0; i < NR2; ++i) {
-          if (k == 0) BK_MFMA0(acc2[i], W2f[k], af[k % D2][i]);
-          else BK_MFMA(acc2[i], W2f[k], af[k % D2][i]);
-        }
-      }
-      BK_MFMA_DRAIN2(acc2[0], acc2[1]);
-      BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
-      const float* sp = s2 + ct1 * 32 + 4 * lh;  // b2 = s2 + 64
-#pragma unroll
-      for (int i = 0; i < NR2; ++i) {
-        char* wp = t1 + ((rb2 + i) * 32 + l31b) * TP + ct1 * 64 + 8 * lh;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(sp + 8 * gq), bv = *reinterpret_cast<const f32x4*>(sp + MID + 8 * gq);
-          u32x2 o;
-          o[0] = relu_pk(pack2(acc2[i][4 * gq] * sv[0] + bv[0], acc2[i][4 * gq + 1] * sv[1] + bv[1]), 0xffffffffu);
-          o[1] = relu_pk(pack2(acc2[i][4 * gq + 2] * sv[2] + bv[2], acc2[i][4 * gq + 3] * sv[3] + bv[3]), 0xffffffffu);
-          *reinterpret_cast<u32x2*>(wp + gq * 16) = o;
-        }
-      }
-    }
-    BK_BAR();  // t2 complete
-
-    // ===== P3: y = relu(bn3(t2 . W3^T) + x) (as bottleneck64_kernel) =============================================================
-    {
-      int lz3;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(lz3));
-      const char* pbase = t1 + (l31 + lz3) * TP + 16 * lh;
-      // conv3's FrozenBN constants of this lane's 64 output channels: from the LDS table, once per patch (in registers for the whole
-      // kernel they would not fit beside the residual, which is live from P1 on in this variant)
-      f32x4 s3r[2][4], b3r[2][4];
-      {
-        const float* sb = bn + 4 * MID + 64 * wave + 4 * lh + lz3;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            s3r[j][gq] = *reinterpret_cast<const f32x4*>(sb + 32 * j + 8 * gq);
-            b3r[j][gq] = *reinterpret_cast<const f32x4*>(sb + C + 32 * j + 8 * gq);
-          }
-      }
-      bf16x8 av[2][4];
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) av[b][ks] = *reinterpret_cast<const bf16x8*>(pbase + b * 32 * TP + ks * 32);
-      f32x16 acc3[2][2];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (ks == 0) BK_MFMA0(acc3[0][j], W3f[j][0], av[0][0]);
-          else BK_MFMA(acc3[0][j], W3f[j][ks], av[0][ks]);
-        }
-#pragma unroll
-      for (int rt = 0; rt < NR3; ++rt) {
-        const int cb = rt & 1, nb = cb ^ 1;
-        BK_MFMA_DRAIN2(acc3[cb][0], acc3[cb][1]);
-        if (rt + 2 < NR3) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) av[cb][ks] = *reinterpret_cast<const bf16x8*>(pbase + (rt + 2) * 32 * TP + ks * 32);
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int j = c >> 2, gq = c & 3;
-          if (rt < NR3 - 1) {
-            const int ks2 = c >> 1, j2 = c & 1;
-            if (ks2 == 0) BK_MFMA0(acc3[nb][j2], W3f[j2][0], av[nb][0]);
-            else BK_MFMA(acc3[nb][j2], W3f[j2][ks2], av[nb][ks2]);
-          }
-          const f32x4 sv = s3r[j][gq], bv = b3r[j][gq];
-          const u32x2 rv = res[rt * 8 + j * 4 + gq];
-          u32x2 o;
-          o[0] = relu_pk(pack2(acc3[cb][j][4 * gq] * sv[0] + bv[0] + __uint_as_float(rv[0] << 16),
-                               acc3[cb][j][4 * gq + 1] * sv[1] + bv[1] + __uint_as_float(rv[0] & 0xffff0000u)), 0xffffffffu);
-          o[1] = relu_pk(pack2(acc3[cb][j][4 * gq + 2] * sv[2] + bv[2] + __uint_as_float(rv[1] << 16),
-                               acc3[cb][j][4 * gq + 3] * sv[3] + bv[3] + __uint_as_float(rv[1] & 0xffff0000u)), 0xffffffffu);
-#ifdef BK_NOSTORE
-          if (o[0] == 0x12345678u) *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
-#else
-          *reinterpret_cast<u32x2*>(yptr[rt] + 64 * j + 16 * gq) = o;
-#endif
-        }
-      }
-    }
-    {  // chunk 0 of the patch after the next into the slot of this patch's chunk 3 (free since B4); its offsets serve that patch's
-       // chunks 1 .. 3 during the next iteration
-      int sp = s0 + 3;
-      sp = sp >= RNSLOT ? sp - RNSLOT : sp;
-      halo_offsets(td2, goff1);
-      issue_chunk(goff1, 0, sp);
-    }
-    t = tn1;
-    tn1 = tn2;
-    td = td1;
-    td1 = td2;
-    s0 = s0 + 4 >= RNSLOT ? s0 + 4 - RNSLOT : s0 + 4;
-  }
-  // the ring ran ahead of the last patch: its LDS-DMA must not outlive the block's LDS allocation
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // First block of res2 (64 -> 64 -> 64 -> 256, projection shortcut), same design.  What differs from the identity block:
 //   * x has 64 channels: a halo is 192 rows x 128 B = 24 KiB, so TWO halo buffers fit and the next patch's halo is issued at
 //     the top of a tile, a whole tile ahead (the identity block can only issue it after conv1);
@@ -1180,10 +795,8 @@ int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
   static int ncu = 256;
   constexpr int lds_stage = 4 * 4096 + 512;  // store staging + position table
   constexpr int lds_big = 192 * 512 + 192 * TP + (4 * MID + 2 * C) * 4 + lds_stage;
-  static_assert(lds_big == LDS_BYTES + lds_stage && lds_big <= 160 * 1024 && RLDS_BYTES <= 160 * 1024, "LDS budget");
-  static const int ring_on = getenv("SYLPH_BK_RING") ? atoi(getenv("SYLPH_BK_RING")) : 0;
+  static_assert(lds_big == LDS_BYTES + lds_stage && lds_big <= 160 * 1024, "LDS budget");
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)bottleneck64r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RLDS_BYTES) != hipSuccess) return -7;
     if (hipFuncSetAttribute((const void*)bottleneck64_kernel<3, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big) != hipSuccess) return -7;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1195,7 +808,6 @@ int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
   if (small) return -1;  // the 64-position double-buffered variant (round 3, measured 1.56 vs 1.31 ms) no longer fits beside the store staging
-  if (ring_on && !small) { hipLaunchKernelGGL(bottleneck64r_kernel, dim3(grid), dim3(256), RLDS_BYTES, s, a); return (int)hipGetLastError(); }
   hipLaunchKernelGGL((bottleneck64_kernel<3, 2, 4, false>), dim3(grid), dim3(256), lds_big, s, a);
   return (int)hipGetLastError();
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of the fused res2 identity bottleneck (bottleneck.hip) at the production shape: B x 200 x 336, C 256, mid 64.
 HIP-event time of the kernel launch alone (sylph_profile), so the layout conversions of the parity entry are not in it.
-Usage (GPU box): [SYLPH_LIB_PATH=lib/variants/...so] [SYLPH_BK_RING=0|1] python tools/bench_bottleneck.py [batch] [iters]"""
+Usage (GPU box): [SYLPH_LIB_PATH=lib/variants/...so] python tools/bench_bottleneck.py [batch] [iters]"""
 import os
 import sys
 
@@ -27,5 +27,5 @@ torch.cuda.synchronize()
 for name, k in eng.profile_read()["kernels"].items():
     ms, fl, n = k["ms"], k["flops"], max(k["launches"], 1)
     pos = B * 200 * 336
-    print(f"{os.environ.get('SYLPH_LIB_PATH', 'product')[-40:]:40s} ring={os.environ.get('SYLPH_BK_RING', '1')} {name:28s} {ms / n * 1e3:8.1f} us/launch  "
+    print(f"{os.environ.get('SYLPH_LIB_PATH', 'product')[-40:]:40s} {name:28s} {ms / n * 1e3:8.1f} us/launch  "
           f"{fl / (ms * 1e-3) / 1e12:7.1f} TFLOP/s  {pos * 1024 / (ms / n * 1e-3) / 1e12:5.2f} TB/s (x once + y once)")
