@@ -528,7 +528,15 @@ bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a) {
          a.Cin >= 32 && a.ss_padded_host && (a.out_ld & 7) == 0 && a.zeros != nullptr;
 }
 
+#ifdef SYLPH_ABLATE
+int launch_conv_hq(const ConvArgs& a, hipStream_t s);  // tools/probes/conv_hpipe4.hip (linked by tools/probes/build_hq.sh only)
+#endif
+
 int launch_conv_hpipe(const ConvArgs& a, hipStream_t s) {
+#if defined(SYLPH_ABLATE) && defined(SYLPH_HQ_PROBE)
+  static const int hq = SYLPH_AB_ENV("SYLPH_CONV_HQ", 0);  // A/B: the four-wave probe kernel on the same tile table and stage images
+  if (hq) return launch_conv_hq(a, s);
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_hpipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return -7;
