@@ -181,7 +181,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   }
   // pointwise bf16 layers: persistent pipelined kernel (conv_pw.hip) when the launch has at least one tile per block slot
   static const int pw_on = getenv("SYLPH_CONV_PW") ? atoi(getenv("SYLPH_CONV_PW")) : 1;
-  bool pw = false;
+  bool pw = false, spw = false;
   int pw_bm = 0, pw_bn = 0;
   if (pw_on && !hpipe && !halo && c->dt == DT_BF16 && !o.out_f32 && L.KH == 1 && L.KW == 1 && o.pad == 0 && !o.stem && o.group_cout == 0 &&
       o.mul_nch == 0 && !o.want_gn && !o.gn_coef && o.cout_override < 0 && L.Cout == L.Cout_pad &&
@@ -202,8 +202,14 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     // conv1 (-13 ... -20 %), conv3 + projection as one GEMM (-14 ... -20 %), FPN laterals incl. the top-down add (-10 ... -15 %) --
     // except the res3-shaped identity conv1 (N = 128, stride 1: already at 5 TB/s in conv_igemm).  With a residual tile to fetch the
     // two kernels are equal (res4 / res5) or conv_igemm's five co-resident blocks win (res3, K = 128): those stay there.
-    const bool pays = o.res_mode != 1 && (L.Cout % 256 == 0 || o.stride != 1);
-    pw = fits && (pw_on == 2 || (tiles >= 256 && pays));
+    // round 5: a same-geometry residual (conv3 of the identity blocks) takes the streaming variant (conv_spw.hip) on the same operands
+    static const int spw_on = getenv("SYLPH_CONV_SPW") ? atoi(getenv("SYLPH_CONV_SPW")) : 1;
+    spw = spw_on && o.res_mode == 1 && o.res && L.Cout % 256 == 0 && L.Cout <= 2048 && (L.Cin == 128 || L.Cin == 256 || (spw_on == 2 && L.Cin == 512)) && o.stride == 1 &&
+          !o.in2 && bm == 128 && bn == 256 && (o.res_ld & 7) == 0 &&
+          (spw_on == 2 || (rows + bm - 1) / bm >= 512);  // a block owns whole M tiles: at least two per CU
+    const bool pays = (o.res_mode != 1 || spw) && (L.Cout % 256 == 0 || o.stride != 1);
+    pw = fits && (pw_on == 2 || spw || (tiles >= 256 && pays));
+    if (!pw) spw = false;
     if (pw) { BM = bm; BN = bn; }
   }
   Geom g;
@@ -239,7 +245,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
       HIPCHK(hipStreamSynchronize(c->stream));
       it = c->pw_weights.emplace(L.w, std::make_pair(wp, tb)).first;
     }
-    a.wt = it->second.first;
+    if (!spw) a.wt = it->second.first;  // conv_spw reads the conv_igemm layout itself (weights in registers)
     a.pw_table = it->second.second;
     if (!c->pw_trash) {
       OwnerScope ctx_owned(c, nullptr);
@@ -367,6 +373,11 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
       });
       return 0;
     }
+  }
+  if (pw && spw) {
+    if (!conv_spw_ok(dt, of32, a)) return fail("internal: conv_spw selected for a layer it cannot run");
+    ops.push_back([a, c, flops](hipStream_t s) { return timed_op(c, "conv_spw_kernel", flops, s, [=](hipStream_t st) { return launch_conv_spw(a, st); }); });
+    return 0;
   }
   if (pw) {
     if (!conv_pw_ok(dt, of32, a)) return fail("internal: conv_pw selected for a layer it cannot run");

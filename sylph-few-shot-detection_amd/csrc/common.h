@@ -160,6 +160,10 @@ bool conv_pw_tile(int cout, int k_total, bool has_res, int* BM, int* BN);
 bool conv_pw_ok(DType dt, bool out_f32, const ConvArgs& a);
 int launch_conv_pw(const ConvArgs& a, int BM, int BN, hipStream_t s);
 int launch_pw_pack_weights(const void* w_igemm, void* w_pw, int Cout, int K, int BN, hipStream_t s);
+// conv_spw.hip: streaming pointwise conv with a same-geometry residual (bottleneck conv3 of identity blocks): conv_pw's operands
+// (stage-image weights for BN = 256, table, one PwDesc per 128-row M tile), four MFMA waves + four streaming waves per CU
+bool conv_spw_ok(DType dt, bool out_f32, const ConvArgs& a);
+int launch_conv_spw(const ConvArgs& a, hipStream_t s);
 int launch_pw_pack_table(const float* scale, const float* shift, float* out, int Cout, int BN, hipStream_t s);
 
 }  // namespace sylph

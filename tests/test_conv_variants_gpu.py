@@ -56,6 +56,18 @@ def test_parity_suite_with_halo_mode_forced():
     _rerun({"SYLPH_CONV_HALO": "2", "SYLPH_CONV_HPIPE": "0"})
 
 
+def test_parity_suite_with_streaming_residual_conv_everywhere():
+    """SYLPH_CONV_SPW=2 routes EVERY bottleneck conv3 with a same-geometry residual (K 128 / 256 / 512) through conv_spw_kernel (weights
+    in registers, A ring, residual and result streamed through the LDS tile buffer by the streaming waves) whatever the launch size --
+    ragged batches, partial last tiles, launches of a few tiles: conv2d vs torch, backbone / episode / full-size checks against the
+    oracle, and the ulp-level block tests."""
+    env = {"SYLPH_CONV_SPW": "2"}
+    _rerun(env, "conv2d or backbone or episode or c3 or full_size")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "bottleneck or stage"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_parity_suite_with_pointwise_kernel_everywhere():
     """SYLPH_CONV_PW=2 routes EVERY eligible bf16 1x1 layer through conv_pw_kernel whatever the launch size -- also the layers the
     default policy leaves on conv_igemm (same-geometry residual: the RES = 1 instantiations; N = 128 identity conv1): conv2d vs
