@@ -204,7 +204,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     // two kernels are equal (res4 / res5) or conv_igemm's five co-resident blocks win (res3, K = 128): those stay there.
     // round 5: a same-geometry residual (conv3 of the identity blocks) takes the streaming variant (conv_spw.hip) on the same operands
     static const int spw_on = getenv("SYLPH_CONV_SPW") ? atoi(getenv("SYLPH_CONV_SPW")) : 1;
-    spw = spw_on && o.res_mode == 1 && o.res && L.Cout % 256 == 0 && L.Cout <= 2048 && (L.Cin == 128 || L.Cin == 256 || (spw_on == 2 && L.Cin == 512)) && o.stride == 1 &&
+    spw = spw_on && o.res_mode == 1 && o.res && L.Cout % 256 == 0 && L.Cout <= 2048 && (L.Cin == 128 || L.Cin == 256 || L.Cin == 512) && o.stride == 1 &&
           !o.in2 && bm == 128 && bn == 256 && (o.res_ld & 7) == 0 &&
           (spw_on == 2 || (rows + bm - 1) / bm >= 512);  // a block owns whole M tiles: at least two per CU
     const bool pays = (o.res_mode != 1 || spw) && (L.Cout % 256 == 0 || o.stride != 1);

@@ -81,6 +81,7 @@ template <int K, bool RELU>
 __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
   constexpr int NK = K / 64;                  // 64-channel phases per tile
   constexpr int KS = K / 16;                  // MFMA k-steps = weight fragments per wave (4 VGPRs each)
+  constexpr int UNR_OUT = K == 512 ? 1 : 4, UNR_IN = K == 512 ? 2 : 16;  // streamer loops: K = 512 leaves no registers to unroll them
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
   bool have_prev = false;
   auto out_prev = [&]() {  // the finished tile out of the buffer: 16-byte stores, 8 lanes per 128-byte line
     const unsigned region = lds0 + BUF_OFF + sg * 16384;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+#pragma unroll UNR_OUT
+    for (int c = 0; c < 4; ++c) {  // (K = 512: not unrolled, a wave holds 128 weight registers)
       u32x4 o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) asm volatile("ds_read_b128 %0, %1" : "=v"(o[k]) : "v"(region + c * 4096 + k * 1024 + lane * 16));
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
   };
   auto res_in = [&](int row0, int seg_rows, int res_row0) {  // this tile's residual rows into the buffer (whole lines, source-side swizzle)
     char* const region_p = smem + BUF_OFF + sg * 16384;
-#pragma unroll
+#pragma unroll UNR_IN
     for (int k = 0; k < 16; ++k) {
       const int rc = 8 * k + r8;
       int pos = row0 + rc;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
     }
     if (streamer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's residual has landed (and the previous tile is out)
     SP_BAR();  // A: K loop done everywhere, residual in the buffer
-    {
+    if constexpr (K <= 256) {
       f32x4v sc4[4], sh4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -283,6 +284,38 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[i][4 * g + e], sc4[g][e], sh4[g][e]);
+          const u32x2 rr = rv[g];
+          v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+          if (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          bf16x2 p0, p1;
+          p0[0] = (bf16_t)v[0]; p0[1] = (bf16_t)v[1]; p1[0] = (bf16_t)v[2]; p1[1] = (bf16_t)v[3];
+          const u32x2 pk = {__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+          asm volatile("ds_write_b64 %0, %1" ::"v"(rg + (((4 * hb + g) ^ (l31 & 7)) << 4)), "v"(pk) : "memory");
+        }
+      }
+    } else {
+      // (scale / shift are re-read per 8-channel group: K = 512 keeps 128 weight registers, there is no room to hold all 32 values)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned rg = region + i * 4096;
+        u32x2 rv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("ds_read_b64 %0, %1" : "=v"(rv[g]) : "v"(rg + (((4 * hb + g) ^ (l31 & 7)) << 4)));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4v sc4, sh4;
+          const int chw = wave * 32 + 8 * g + 4 * lh;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(sc4) : "v"(tab + chw * 4));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(sh4) : "v"(tab + (BN + chw) * 4));
+          if (g == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc4), "+v"(sh4), "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc4), "+v"(sh4));
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[i][4 * g + e], sc4[e], sh4[e]);
           const u32x2 rr = rv[g];
           v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
           v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
