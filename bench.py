@@ -60,7 +60,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="query images per GPU per step")
+    ap.add_argument("--batch", type=int, default=96,
+                    help="query images per GPU per step (round 5: 96 -- 2 155-2 164 img/s vs 2 112-2 132 at 64 on one box: launch tails; "
+                         "activations stay below the 4-GiB range of the kernels' 32-bit offsets up to 112)")
     ap.add_argument("--ways", type=int, default=5)
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--height", type=int, default=800)
@@ -75,6 +77,9 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=3)
     ap.add_argument("--no-sweep", action="store_true", help="skip the untimed batch-size sweep / fp32 legs")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-oracle agreement leg")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes of a short child run of this script); "
+                         "the committed profiles/r5_pmc_hbm_traffic.json is used instead if its source fingerprint matches")
     ap.add_argument("--dump-codes", default=None, help="rank 0 writes the gathered, normalised class codes (N x 257) to this .pt file (tests)")
     args = ap.parse_args()
 
@@ -200,7 +205,7 @@ def main():
     sweep, fp32_img_s, parity, host_u8_img_s = None, None, None, None
     if rank == 0 and world == 1 and not args.no_sweep:
         sweep = {}
-        for b in (1, 8, 16, 64):
+        for b in (1, 8, 16, 64, 96):
             if b == B:
                 continue
             qs = queries[:b] if b <= B else dev_images(b, H, Wd, 7, device)
@@ -331,6 +336,8 @@ def main():
         images_timed = B * args.steps
         alg_flops = GFLOP_PER_IMAGE_MFMA_CONV * 1e9 * images_timed  # all conv launches of the region, this rank
         achieved = alg_flops / conv_s / 1e12 if conv_s > 0 else 0.0
+        if not args.no_live_pmc and world == 1 and args.dtype == "bf16":
+            collect_live_pmc(B)  # two short rocprofv3 --pmc passes of this command, after the timed region (N = 1 only)
         traffic, traffic_src = pmc_traffic_per_launch(B, launches // max(args.steps, 1))
         roofline = {
             "kernel": "conv_hpipe_kernel + conv_igemm_kernel + bottleneck64[p]_kernel + stem_pool_kernel + gn_logits / gn_taps: the MFMA conv launches (and the fused passes that replace convs) of the timed region",
@@ -501,20 +508,61 @@ def baseline_config_legs(args, device, local_rank):
     return legs
 
 
+_LIVE_PMC = None  # the summary collected by collect_live_pmc() in THIS run
+
+
+def collect_live_pmc(batch):
+    """roofline.traffic collected in the run itself: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE,
+    each with --kernel-trace only, as MI355X_MICROARCH.md prescribes: separate passes) of a short child run of this same script at the
+    same batch, summarised by tools/rocpd_pmc.py (last query step; FETCH_SIZE doubled on gfx950).  Any failure leaves the committed
+    profiles/r5_pmc_hbm_traffic.json (fingerprint-checked) as the source."""
+    global _LIVE_PMC
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("SYLPH_BENCH_PMC_CHILD") or shutil.which("rocprofv3") is None:
+        return
+    tmp = tempfile.mkdtemp(prefix="sylph_pmc_", dir="/tmp")
+    env = dict(os.environ, SYLPH_BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(batch), "--steps", "2", "--warmup", "2", "--no-cpu-baseline",
+             "--no-kernel-events", "--no-sweep", "--no-parity", "--no-live-pmc"]
+    try:
+        for counter, tag in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", os.path.join(tmp, tag), "-o", tag, "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            if r.returncode != 0 or not os.path.exists(os.path.join(tmp, tag, f"{tag}_results.db")):
+                print(f"bench.py: live PMC pass {counter} failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+                return
+        out = os.path.join(tmp, "pmc.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_pmc.py"), os.path.join(tmp, "f", "f_results.db"),
+                            os.path.join(tmp, "w", "w_results.db"), str(batch), out], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            print(f"bench.py: tools/rocpd_pmc.py failed: {r.stderr[-300:]}", file=sys.stderr)
+            return
+        with open(out) as f:
+            _LIVE_PMC = json.load(f)
+    except Exception as e:  # noqa: BLE001 -- measurement aid: never fail the bench line
+        print(f"bench.py: live PMC collection failed: {e}", file=sys.stderr)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _pmc_file():
     """The committed PMC summary of THIS build (tools/collect_profiles.sh -> tools/rocpd_pmc.py), or (None, reason): a summary whose
     kernel-source fingerprint differs from the tree is measured on other kernels and is refused -- loudly, no fall-back to older rounds."""
+    if _LIVE_PMC is not None:
+        return _LIVE_PMC, "collected in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a 2-step child run)"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from rocpd_pmc_fingerprint import csrc_fingerprint
-    path = os.path.join(ROOT, "profiles", "r4_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r5_pmc_hbm_traffic.json")
     if not os.path.exists(path):
-        return None, "profiles/r4_pmc_hbm_traffic.json is missing"
+        return None, "profiles/r5_pmc_hbm_traffic.json is missing"
     with open(path) as f:
         d = json.load(f)
     if d.get("csrc_fingerprint") != csrc_fingerprint():
-        return None, (f"profiles/r4_pmc_hbm_traffic.json was collected on other kernel sources (fingerprint {d.get('csrc_fingerprint')} != "
+        return None, (f"profiles/r5_pmc_hbm_traffic.json was collected on other kernel sources (fingerprint {d.get('csrc_fingerprint')} != "
                       f"{csrc_fingerprint()}): re-run tools/collect_profiles.sh")
-    return d, "profiles/r4_pmc_hbm_traffic.json"
+    return d, "profiles/r5_pmc_hbm_traffic.json"
 
 
 def pmc_per_kernel_bytes(batch):
@@ -525,7 +573,7 @@ def pmc_per_kernel_bytes(batch):
     out = {}
     for k, v in d.get("per_kernel_hbm_bytes_per_image", {}).items():
         kk = k
-        for tag in ("conv_igemm_kernel", "conv_pw_kernel", "conv_hpipe_kernel<true>", "conv_hpipe_kernel<false>", "bottleneck64p_kernel",
+        for tag in ("conv_igemm_kernel", "conv_pw_kernel", "conv_spw_kernel", "conv_hpipe_kernel<true>", "conv_hpipe_kernel<false>", "bottleneck64p_kernel",
                     "bottleneck64_kernel", "stem_pool_kernel", "gn_logits_kernel", "gn_taps_kernel"):
             if tag in k:
                 kk = tag
@@ -545,7 +593,7 @@ def pmc_traffic_per_launch(batch, launches_per_step):
     return round(d["hbm_bytes_per_image"] * batch / launches_per_step), {
         "file": src, "profiled_batch": d.get("batch"), "hbm_bytes_per_image": round(d["hbm_bytes_per_image"]),
         "csrc_fingerprint": d.get("csrc_fingerprint"),
-        "note": "separate rocprofv3 --pmc passes of this command on these kernel sources (not collected in this run)"}
+        "note": "separate rocprofv3 --pmc passes of this command on these kernel sources"}
 
 
 def parity_bf16(sd, queries, cls_conv, cls_bias, dets):

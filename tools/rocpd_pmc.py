@@ -26,7 +26,7 @@ def last_step(dbfile, counter):
     idx = first[-1]
     step = rows[idx:]
     # every launch bench.py times as conv work (sylph_profile_*): the conv kernels proper and the fused passes that replace convs
-    CONV = ("conv_igemm_kernel", "conv_hpipe_kernel", "conv_pw_kernel", "bottleneck64", "stem_pool_kernel", "stem_conv_kernel", "gn_logits_kernel",
+    CONV = ("conv_igemm_kernel", "conv_hpipe_kernel", "conv_pw_kernel", "conv_spw_kernel", "bottleneck64", "stem_pool_kernel", "stem_conv_kernel", "gn_logits_kernel",
             "gn_taps_kernel", "tap_gather_kernel")
     conv = [r for r in step if any(k in r[0] for k in CONV)]
     pre = step[0][1]
