@@ -74,14 +74,16 @@ def backbone_state_dict(seed: int = 0, depth: int = 50) -> Dict[str, torch.Tenso
 
 
 def head_state_dict(seed: int = 1, num_classes: int = 60, c: int = 256, num_convs: int = 4,
-                    levels: int = 5, num_share_convs: int = 0, norm: str = "GN") -> Dict[str, torch.Tensor]:
+                    levels: int = 5, num_share_convs: int = 0, norm: str = "GN", num_cls_convs: int = None,
+                    num_box_convs: int = None) -> Dict[str, torch.Tensor]:
     """MetaFCOSHead weights under the reference's keys.  norm "GN": a tower is nn.Sequential(conv, GroupNorm, ReLU) x n (indices 3i,
     3i + 1); norm "none": (conv, ReLU) x n (index 2i) -- fcos.py:72-122.  num_share_convs: the shared tower in front of both."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     p = "proposal_generator.fcos_head"
     step = 3 if norm == "GN" else 2
-    for t, n in (("cls_tower", num_convs), ("bbox_tower", num_convs)):
+    for t, n in (("cls_tower", num_convs if num_cls_convs is None else num_cls_convs),
+                 ("bbox_tower", num_convs if num_box_convs is None else num_box_convs)):  # MODEL.FCOS.NUM_CLS_CONVS / NUM_BOX_CONVS
         for i in range(n):
             sd[f"{p}.{t}.{step * i}.weight"] = _conv(g, c, c, 3, std=math.sqrt(2.0 / (9 * c)))
             sd[f"{p}.{t}.{step * i}.bias"] = torch.randn(c, generator=g) * 0.1

@@ -260,6 +260,48 @@ def gen_owd_decode():
     np.savez_compressed(os.path.join(HERE, "g1d_owd_decode.npz"), **out)
 
 
+TOWER_DEPTH_CASES = (("c2b3", 2, 3, 0, "GN"), ("c1b4_share1", 1, 4, 1, "GN"), ("c3b1_nonorm", 3, 1, 0, "none"), ("c0b2", 0, 2, 0, "GN"))
+
+
+def gen_tower_depths():
+    """MetaFCOSHead with UNEQUAL tower depths (MODEL.FCOS.NUM_CLS_CONVS != NUM_BOX_CONVS, fcos.py:84-122: the two towers are built
+    separately; the HIP path stacks them into one launch per layer only when the depths are equal, so unequal depths take other code)
+    -- with and without the shared tower, with and without GroupNorm, and a cls tower of depth 0 (the class-conditional conv reads the
+    pyramid / shared features directly).  Head outputs + proposals of the reference on g1's pyramid.  VERDICT r4 next #1 (re-audit of
+    the round-4 branch additions with inputs that can see them)."""
+    from sylph.modeling.meta_fcos.fcos import MetaFCOS
+    from ref_shim import ShapeSpec
+    shapes = {f"p{l}": ShapeSpec(channels=256, stride=2 ** l) for l in range(3, 8)}
+    H, Wd, B = 128, 160, 2
+    feats = feature_pyramid(B, H, Wd, seed=11)
+    image_sizes = [(H, Wd - 7), (H - 5, Wd)]
+    codes = W.synthetic_codes(5, seed=35, scale=2.0)
+    out = {"cls_conv": codes["cls_conv"].numpy(), "cls_bias": codes["cls_bias"].numpy(), "image_sizes": np.array(image_sizes)}
+    with torch.no_grad():
+        for tag, nc, nb, share, norm in TOWER_DEPTH_CASES:
+            cfg = make_cfg()
+            cfg.MODEL.FCOS.NUM_CLS_CONVS, cfg.MODEL.FCOS.NUM_BOX_CONVS = nc, nb
+            cfg.MODEL.FCOS.NUM_SHARE_CONVS, cfg.MODEL.FCOS.NORM = share, norm
+            sd = W.head_state_dict(seed=1, num_classes=60, num_share_convs=share, norm=norm, num_cls_convs=nc, num_box_convs=nb)
+            model = MetaFCOS(cfg, shapes).eval()
+            missing = load_prefixed(model, sd, "proposal_generator")
+            assert not [m for m in missing if "tower" in m], missing
+            out[f"{tag}_weights_checksum"] = checksum(sd, "proposal_generator")
+            logits, reg, ctr, iou, _, _ = model.fcos_head(feats, None, False, codes)
+            for l in range(5):
+                out[f"{tag}_logits{l}"] = logits[l].numpy()
+                out[f"{tag}_reg{l}"] = reg[l].numpy()
+                out[f"{tag}_ctr{l}"] = ctr[l].numpy()
+                out[f"{tag}_iou{l}"] = iou[l].numpy()
+            locations = model.compute_locations(feats)
+            props = model.fcos_outputs.predict_proposals(logits, reg, ctr, iou, locations, image_sizes, [])
+            for i, p in enumerate(props):
+                out.update(inst_to_np(p, f"{tag}_img{i}"))
+            out[f"{tag}_count"] = np.array([len(p) for p in props])
+            print("tower depths", tag, [len(p) for p in props], float(logits[0].abs().max()))
+    np.savez_compressed(os.path.join(HERE, "g1e_tower_depths.npz"), **out)
+
+
 def gen_codegen():
     from sylph.modeling.code_generator.code_generator import CodeGenerator
     from ref_shim import Boxes, Instances
@@ -518,7 +560,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     np.random.seed(0)
     only = sys.argv[1:]  # e.g. `gen_goldens.py gen_codegen_s10` regenerates one fixture
-    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_owd_decode, gen_codegen, gen_codegen_variants, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
+    for fn in (gen_head_decode, gen_decode_variants, gen_head_variants, gen_owd_decode, gen_tower_depths, gen_codegen, gen_codegen_variants, gen_codegen_weight_scale, gen_codegen_s10, gen_reduce_condblock, gen_roi_encoder):
         if not only or fn.__name__ in only:
             fn()
     print("done")

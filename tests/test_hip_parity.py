@@ -170,6 +170,46 @@ def test_head_variants_match_reference_golden(g1, golden_dir, tag, share, norm, 
         np.testing.assert_allclose(d["scores"].cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tag,nc,nb,share,norm", [("c2b3", 2, 3, 0, "GN"), ("c1b4_share1", 1, 4, 1, "GN"), ("c3b1_nonorm", 3, 1, 0, "none"),
+                                                   ("c0b2", 0, 2, 0, "GN")])
+def test_unequal_tower_depths_match_reference_golden(g1, golden_dir, tag, nc, nb, share, norm, dtype):
+    """MODEL.FCOS.NUM_CLS_CONVS != NUM_BOX_CONVS (the HIP path stacks the two towers into one launch per layer only for equal depths:
+    unequal depths take the un-paired plan), with / without the shared tower and GroupNorm, a depth-0 cls tower -- against goldens
+    generated from the reference (g1e).  fp32: head outputs <= 1e-3 and the reference's (level, location, class) set; bf16: head
+    outputs to bf16 tolerance.  VERDICT r4 next #1 (re-audit of the round-4 branch additions)."""
+    from oracle.decode import detector_postprocess
+    from sylph_amd import synthetic as W
+    g = np.load(os.path.join(golden_dir, "g1e_tower_depths.npz"))
+    cfg = _cfg(**{"MODEL.FCOS.NUM_CLS_CONVS": nc, "MODEL.FCOS.NUM_BOX_CONVS": nb, "MODEL.FCOS.NUM_SHARE_CONVS": share, "MODEL.FCOS.NORM": norm})
+    eng = _engine(dtype, cfg)
+    eng.load_state_dict(W.head_state_dict(seed=1, num_classes=60, num_share_convs=share, norm=norm, num_cls_convs=nc, num_box_convs=nb))
+    sizes = [tuple(int(v) for v in s) for s in g["image_sizes"]]
+    eng.import_pyramid(_feats(g1), (128, 160), sizes)
+    eng.head(torch.from_numpy(g["cls_conv"]), torch.from_numpy(g["cls_bias"]))
+    lo, rg, ct, io = eng.export_head()
+    tol = 1e-3 if dtype == "f32" else 6e-2
+    for l in range(5):
+        for name, got in (("logits", lo), ("reg", rg), ("ctr", ct), ("iou", io)):
+            ref = g[f"{tag}_{name}{l}"]
+            assert np.abs(got[l].cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max()), f"{name} level {l}"
+    if dtype != "f32":
+        return
+    dets = eng.decode()
+    key = lambda x: np.lexsort((x["pred_classes"].cpu().numpy(), x["locations"].cpu().numpy()[:, 0], x["locations"].cpu().numpy()[:, 1],
+                                x["fpn_levels"].cpu().numpy()))
+    for i, d in enumerate(dets):
+        pre = f"{tag}_img{i}"
+        ref = {k: torch.from_numpy(g[f"{pre}_{k}"]) for k in ("pred_boxes", "scores", "pred_classes", "fpn_levels", "locations")}
+        ref = detector_postprocess(ref, sizes[i], sizes[i][0], sizes[i][1])
+        # (the HIP head's outputs differ from the reference's by ~1e-6: near-tied scores may swap places in the sorted output and one
+        #  candidate at the post-NMS cut may differ, so the sets are compared with a tolerance of one detection)
+        og, orf = key(d), key(ref)
+        gk = set(zip(d["fpn_levels"].cpu().numpy()[og].tolist(), map(tuple, d["locations"].cpu().numpy()[og].tolist()), d["pred_classes"].cpu().numpy()[og].tolist()))
+        rk = set(zip(ref["fpn_levels"].numpy()[orf].tolist(), map(tuple, ref["locations"].numpy()[orf].tolist()), ref["pred_classes"].numpy()[orf].tolist()))
+        assert len(gk ^ rk) <= 2 and abs(len(gk) - len(rk)) <= 1 and len(rk) > 0, (len(gk), len(rk), len(gk ^ rk))
+
+
 OWD_CASES = [("ctr", ["ctrness"], False, 0.05, 0.6, 100), ("iou", ["iou"], False, 0.05, 0.6, 100), ("ctriou", ["ctrness", "iou"], False, 0.05, 0.6, 100),
              ("ctr_twc", ["ctrness"], True, 0.05, 0.6, 100), ("ctr_t20", ["ctrness"], False, 0.02, 0.6, 100),
              ("ctr_all", ["ctrness"], False, 0.05, 1.0, 1000), ("ctriou_all", ["ctrness", "iou"], False, 0.05, 1.0, 1000),

@@ -99,6 +99,32 @@ def test_head_variants_match_reference(g1, golden_dir, tag, share, norm, owd):
         np.testing.assert_allclose(p["pred_boxes"].numpy(), g[f"{pre}_pred_boxes"], atol=1e-4, rtol=1e-6)
 
 
+TOWER_DEPTH_CASES = [("c2b3", 2, 3, 0, "GN"), ("c1b4_share1", 1, 4, 1, "GN"), ("c3b1_nonorm", 3, 1, 0, "none"), ("c0b2", 0, 2, 0, "GN")]
+
+
+@pytest.mark.parametrize("tag,nc,nb,share,norm", TOWER_DEPTH_CASES)
+def test_unequal_tower_depths_match_reference(g1, golden_dir, tag, nc, nb, share, norm):
+    """MODEL.FCOS.NUM_CLS_CONVS != NUM_BOX_CONVS (fcos.py:84-122), with / without the shared tower and GroupNorm, depth-0 cls tower:
+    the reference's head outputs and proposals (g1e_tower_depths.npz)."""
+    g = _load(golden_dir, "g1e_tower_depths.npz")
+    sd = W.head_state_dict(seed=1, num_classes=60, num_share_convs=share, norm=norm, num_cls_convs=nc, num_box_convs=nb)
+    assert abs(_checksum(sd, "proposal_generator") - float(g[f"{tag}_weights_checksum"])) < 1e-3
+    codes = {"cls_conv": torch.from_numpy(g["cls_conv"]), "cls_bias": torch.from_numpy(g["cls_bias"])}
+    logits, regs, ctrs, ious = H.fcos_head(_feats(g1), sd, codes, num_share_convs=share, norm=norm, num_cls_convs=nc, num_box_convs=nb)
+    for l in range(5):
+        for got, name in ((logits, "logits"), (regs, "reg"), (ctrs, "ctr"), (ious, "iou")):
+            np.testing.assert_allclose(got[l].numpy(), g[f"{tag}_{name}{l}"], atol=TOL, rtol=TOL)
+    ref = lambda k: [torch.from_numpy(g[f"{tag}_{k}{l}"]) for l in range(5)]
+    props = D.predict_proposals(ref("logits"), ref("reg"), ref("ctr"), ref("iou"))
+    for i, p in enumerate(props):
+        pre = f"{tag}_img{i}"
+        assert p["scores"].numel() == int(g[f"{tag}_count"][i])
+        np.testing.assert_array_equal(p["pred_classes"].numpy(), g[f"{pre}_pred_classes"])
+        np.testing.assert_array_equal(p["fpn_levels"].numpy(), g[f"{pre}_fpn_levels"])
+        np.testing.assert_array_equal(p["locations"].numpy(), g[f"{pre}_locations"])
+        np.testing.assert_allclose(p["scores"].numpy(), g[f"{pre}_scores"], atol=1e-6, rtol=1e-6)
+
+
 OWD_CASES = [("ctr", ["ctrness"], False, 0.05, 0.6, 100), ("iou", ["iou"], False, 0.05, 0.6, 100), ("ctriou", ["ctrness", "iou"], False, 0.05, 0.6, 100),
              ("ctr_twc", ["ctrness"], True, 0.05, 0.6, 100), ("ctr_t20", ["ctrness"], False, 0.02, 0.6, 100),
              ("ctr_all", ["ctrness"], False, 0.05, 1.0, 1000), ("ctriou_all", ["ctrness", "iou"], False, 0.05, 1.0, 1000),
