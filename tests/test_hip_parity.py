@@ -48,6 +48,11 @@ CONV_CASES = [
     (256, 20, 1, 1, 0, 16, 20, 2, False, False),
     (512, 1024, 1, 1, 0, 8, 10, 1, True, True),
     (256, 256, 3, 1, 1, 7, 7, 5, True, False),
+    # conv3 + same-geometry residual of the identity blocks (K 128 / 256 / 512): conv_igemm here (few tiles), conv_spw_kernel under
+    # SYLPH_CONV_SPW=2 (tests/test_conv_variants_gpu.py): ragged rows (221 / 189 / 77 per image: partial last tiles), ReLU on and off
+    (128, 512, 1, 1, 0, 17, 13, 2, True, True),
+    (256, 1024, 1, 1, 0, 9, 21, 3, False, True),
+    (512, 2048, 1, 1, 0, 7, 11, 2, True, True),
 ]
 
 
