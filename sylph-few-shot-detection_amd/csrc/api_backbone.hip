@@ -97,8 +97,34 @@ int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block&
   }
   ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
   RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
-  ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
-  RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
+  // res3 conv2 (3x3, 128 -> 128, stride 1), bf16: weights in registers, LDS holds only the activation halo (conv_rw3.hip)
+  static const int rw3_on = getenv("SYLPH_CONV_RW3") ? atoi(getenv("SYLPH_CONV_RW3")) : 1;
+  const bool rw3 = rw3_on && dt == DT_BF16 && mid == 128 && s3 == 1 && blk.c2.Cin == 128 && blk.c2.Cout_pad == 128 && blk.c2.KH == 3 && blk.c2.KW == 3 &&
+                   blk.c2.scale && blk.c2.shift && (size_t)B * H1 * W1 * 256 < ((size_t)1 << 32) &&
+                   (rw3_on == 2 || (size_t)B * H1 * W1 >= (size_t)256 * 120);
+  int ph = 0, pw = 0;
+  if (rw3) pick_patch(H1, W1, 128, 184, 2, &ph, &pw);  // 100 x 168 -> 10 x 12 patches (halo 12 x 14 = 168 rows)
+  if (rw3 && conv_rw3_patch_ok(ph, pw)) {
+    BottleneckArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.x = t1; ba.y = t2;
+    ba.w2 = (const __bf16*)blk.c2.w; ba.s2 = blk.c2.scale; ba.b2 = blk.c2.shift;
+    std::vector<SegDesc> sg = image_segs(B, H1, W1, H1, W1);
+    std::vector<BkTile> bt;
+    for (size_t si2 = 0; si2 < sg.size(); ++si2)
+      for (int yy = 0; yy < H1; yy += ph)
+        for (int xx = 0; xx < W1; xx += pw)
+          bt.push_back(BkTile{sg[si2].in_row0, H1, W1, (yy << 16) | xx, ph, pw, (65536u + pw - 1) / pw, (65536u + pw + 2 - 1) / (pw + 2)});
+    void* btd = nullptr;
+    RET(upload(c, &btd, bt.data(), bt.size() * sizeof(BkTile)));
+    ba.bk = (const BkTile*)btd;
+    ba.n_tiles = (int)bt.size();
+    const double fl = 2.0 * (double)B * H1 * W1 * 128.0 * 1152.0;
+    ops.push_back([=](hipStream_t s) { return timed_op(c, "conv_rw3_kernel", fl, s, [=](hipStream_t st) { return launch_conv_rw3(ba, st); }); });
+  } else {
+    ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
+    RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
+  }
   if (blk.fused_sc) {
     // conv3 + projection shortcut as ONE pointwise GEMM over K = [t2 | X(strided)]: the shortcut
     // tensor is never written to / re-read from HBM

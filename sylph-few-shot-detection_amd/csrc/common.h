@@ -153,6 +153,8 @@ int launch_conv_hpipe(const ConvArgs& a, hipStream_t s);
 int launch_hpipe_pack_weights(const void* w_igemm, void* w_hpipe, int Cout, int Cin, hipStream_t s);  // a.wt of an hpipe launch
 int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s);   // bottleneck.hip: identity block, persistent, weights in registers; small: 64-position patches, double-buffered halo
 int launch_bottleneck64p(const BottleneckArgs& a, hipStream_t s);  // first block of res2: x [pos][64], w3 = [256][128] packed [W3 | Wsc], y = relu(acc + b3)
+int launch_conv_rw3(const BottleneckArgs& a, hipStream_t s);  // conv_rw3.hip: 3x3 s1 128 -> 128 + FrozenBN + ReLU, weights in registers (x, y, w2, s2, b2, bk, n_tiles)
+bool conv_rw3_patch_ok(int ph, int pw);
 void conv_set_nbuf(int n);  // 1: single LDS stage (max occupancy), 2: double-buffered
 // conv_pw.hip: persistent pipelined pointwise (1x1) conv, bf16; a.wt = the layer's stage-image weights (launch_pw_pack_weights),
 // a.tiles = BM-row tiles, a.pw_desc / a.pw_table as below; (BM, BN) from conv_pw_tile (false: not eligible)
