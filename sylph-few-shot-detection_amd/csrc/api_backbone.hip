@@ -100,7 +100,7 @@ int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block&
   // res3 conv2 (3x3, 128 -> 128, stride 1), bf16: weights in registers, LDS holds only the activation halo (conv_rw3.hip)
   static const int rw3_on = getenv("SYLPH_CONV_RW3") ? atoi(getenv("SYLPH_CONV_RW3")) : 1;
   const bool rw3 = rw3_on && dt == DT_BF16 && mid == 128 && s3 == 1 && blk.c2.Cin == 128 && blk.c2.Cout_pad == 128 && blk.c2.KH == 3 && blk.c2.KW == 3 &&
-                   blk.c2.scale && blk.c2.shift && (size_t)B * H1 * W1 * 256 < ((size_t)1 << 32) &&
+                   blk.c2.scale && blk.c2.shift && (size_t)B * H1 * W1 * 256 < ((size_t)1 << 31) &&  // (2 GiB buffer descriptors)
                    (rw3_on == 2 || (size_t)B * H1 * W1 >= (size_t)256 * 120);
   int ph = 0, pw = 0;
   if (rw3) pick_patch(H1, W1, 128, 184, 2, &ph, &pw);  // 100 x 168 -> 10 x 12 patches (halo 12 x 14 = 168 rows)

@@ -158,6 +158,7 @@ BLOCKS = [
     ("res2 identity (bottleneck64_kernel)", 256, 64, 256, 200, 336, 1, False, 2),
     ("res2 first block (bottleneck64p_kernel)", 64, 64, 256, 200, 336, 1, True, 2),
     ("res3 identity", 512, 128, 512, 100, 168, 1, False, 4),
+    ("res3 identity ragged map (conv_rw3 / conv_spw edge patches and partial tiles)", 512, 128, 512, 93, 157, 1, False, 4),
     ("res3 first block (stride 2, conv3 + projection as one GEMM)", 256, 128, 512, 200, 336, 2, True, 4),
     ("res4 identity (conv2 on conv_hpipe)", 1024, 256, 1024, 50, 84, 1, False, 32),
     ("res5 first block", 1024, 512, 2048, 50, 84, 2, True, 16),

@@ -68,6 +68,17 @@ def test_parity_suite_with_streaming_residual_conv_everywhere():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_parity_suite_with_register_weight_conv2_everywhere():
+    """SYLPH_CONV_RW3=2 routes every stride-1 128 -> 128 3x3 bottleneck conv2 whose patch shape fits (conv_rw3_patch_ok) through
+    conv_rw3_kernel whatever the launch size -- launches of a few patches, fewer patches than CUs, one-patch images: backbone / episode /
+    full-size checks against the oracle and the ulp-level block tests."""
+    env = {"SYLPH_CONV_RW3": "2"}
+    _rerun(env, "backbone or episode or bottleneck or full_size")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "bottleneck or stage"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_parity_suite_with_pointwise_kernel_everywhere():
     """SYLPH_CONV_PW=2 routes EVERY eligible bf16 1x1 layer through conv_pw_kernel whatever the launch size -- also the layers the
     default policy leaves on conv_igemm (same-geometry residual: the RES = 1 instantiations; N = 128 identity conv1): conv2d vs
