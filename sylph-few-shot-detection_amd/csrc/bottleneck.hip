@@ -70,6 +70,13 @@ constexpr int LDS_BYTES = BN_OFF + (4 * MID + 2 * C) * 4;  // 129 024
 #undef BK_NOX
 #undef BK_NOE3
 #undef BK_NOSTORE
+#undef BK_TIMING
+#endif
+// BK_TIMING (SYLPH_ABLATE builds): s_memtime stamps of the phases of patch 10, printed by block 8 (tools/bench_bottleneck.py shows them)
+#ifdef BK_TIMING
+#define BK_STAMP(i) do { if (it == 10) ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BK_STAMP(i) do { } while (0)
 #endif
 #ifndef BK_ONLY
 #define BK_ONLY 0
@@ -201,7 +208,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     return __builtin_bit_cast(unsigned, v);
   };
 
+#ifdef BK_TIMING
+  unsigned long long ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int it = 0; t < a.n_tiles; ++it) {
+#ifdef BK_TIMING
+    if (it == 11) ts[11] = __builtin_readcyclecounter();
+#endif
+    BK_STAMP(0);
     const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
     const int PW = td[5], HW2 = PW + 2, HR = (td[4] + 2) * HW2, NPOS = td[4] * PW;
     const unsigned inv_pw = (unsigned)td[6], inv_hw2 = (unsigned)td[7];
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     BK_BAR();  // ... for every wave; t1 / t2 of the previous tile are free
+    BK_STAMP(1);
     // y byte offset of patch position m (0xffffffff: no such pixel -> the store goes to the trash slot), for the transposed stores of
     // P3: entry [m >> 5][m & 7][(m >> 3) & 3], so that a lane reads the four rows it stores of a row tile with one ds_read_b128.
     // (The previous patch's P3 is over for every wave -- barrier above; the next reader is this patch's P3, three barriers on.)
@@ -272,6 +287,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       }
       if constexpr (NR1 == 3) BK_MFMA_DRAIN3(acc1[0], acc1[1], acc1[2]);
       else BK_MFMA_DRAIN2(acc1[0], acc1[1]);
+      BK_STAMP(2);
       const float* sp = s1 + ct1 * 32 + 4 * lh;  // b1 = s1 + 64
 #pragma unroll
       for (int i = 0; i < NR1; ++i) {
@@ -290,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
         }
       }
     }
+    BK_STAMP(3);
     // residual values of this lane's conv3 outputs (positions rt * 32 + l31, channels 64 wave + 32 j + 8 gq + 4 lh ..): halo -> registers
     u32x2 res[NR3 * 8];
     int lzr;
@@ -314,10 +331,13 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       asm volatile(""
                    : "+v"(res[16]), "+v"(res[17]), "+v"(res[18]), "+v"(res[19]), "+v"(res[20]), "+v"(res[21]), "+v"(res[22]), "+v"(res[23]),
                      "+v"(res[24]), "+v"(res[25]), "+v"(res[26]), "+v"(res[27]), "+v"(res[28]), "+v"(res[29]), "+v"(res[30]), "+v"(res[31]));
+    BK_STAMP(4);
     BK_BAR();  // t1 complete; every wave is done with the x halo
+    BK_STAMP(5);
 #ifndef BK_NOX
     if (!DB && t_next < a.n_tiles) issue_x(td_next, xb);
 #endif
+    BK_STAMP(6);
 
     // ===== P2: t2 = relu(bn2(conv3x3(t1))), row tiles rb2, rb2+1, channels ct1 ===============================================
     // t1 / t2 rows are PADDED to 144 B (they are written by ds_write, not by DMA): conflict-free without a swizzle, so the
@@ -381,7 +401,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       }
       if constexpr (NR2 == 2) BK_MFMA_DRAIN2(acc2[0], acc2[1]);
       else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc2[0])::"memory");
+      BK_STAMP(7);
       BK_BAR();  // every wave has finished reading t1: t2 may overwrite it
+      BK_STAMP(8);
       const float* sp = s2 + ct1 * 32 + 4 * lh;  // b2 = s2 + 64
 #pragma unroll
       for (int i = 0; i < NR2; ++i) {
@@ -396,7 +418,9 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
         }
       }
     }
+    BK_STAMP(9);
     BK_BAR();  // t2 complete
+    BK_STAMP(10);
 
     // ===== P3: y = relu(bn3(t2 . W3^T) + x), all four row tiles, channels 64 wave .. 64 wave + 63 ==========================
     // Software pipelined over the row tiles: the 8 MFMAs of tile rt + 1 are issued one per epilogue chunk of tile rt (k-step
@@ -476,6 +500,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
     td = td_next;
     if (DB) xb = xb == smem ? smem + XBB : smem;
   }
+#ifdef BK_TIMING
+  if (blockIdx.x == 8 && lane == 0)
+    printf("wave %d: wait+bar %llu | P1 K %llu  epi %llu  res copy %llu  bar %llu | issue_x %llu  P2 K %llu  bar %llu  epi %llu  bar %llu | P3 %llu | total %llu\n", wave,
+           ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[8] - ts[7], ts[9] - ts[8],
+           ts[10] - ts[9], ts[11] - ts[10], ts[11] - ts[0]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
