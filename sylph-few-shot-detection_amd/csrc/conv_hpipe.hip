@@ -60,6 +60,7 @@
 #undef HP_NOLDS
 #undef HP_NOLOAD
 #undef HP_NOEPI
+#undef HP_TIMING
 #endif
 
 namespace sylph {
@@ -114,6 +115,10 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   const int nt = q0 - m_local * a.n_ntiles;
   const int mt = xcd * chunk + m_local;
   if (m_local >= chunk || mt >= a.n_mtiles) return;
+#ifdef HP_TIMING  // (SYLPH_ABLATE builds) s_memtime stamps of a block's prologue / K loop / epilogue, printed by 64 blocks of a launch
+  const unsigned long long hp_t0 = __builtin_readcyclecounter();
+  unsigned long long hp_t1 = 0, hp_t2 = 0;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,6 +370,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
     HP_WAITL();
   }
   HP_BAR();     // B_0
+#ifdef HP_TIMING
+  hp_t1 = __builtin_readcyclecounter();
+#endif
 
   // vmcnt immediates: a wave needs its loads of phase q+1 (issued in L(q-2)) landed before B_{2q+2}; the loads issued after
   // them are the groups of L(q-1) and L(q).  Row 0 waits at the end of M(q) (seg 2q+1), row 1 at the end of L(q) (seg 2q+1).
@@ -402,6 +410,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-page tail loads must not land in the epilogue tile
   __syncthreads();
+#ifdef HP_TIMING
+  hp_t2 = __builtin_readcyclecounter();
+#endif
 
   // ---- fused epilogue: per patch two 64-row passes through an fp32 LDS tile ---------------------------------------
   float* const sC = reinterpret_cast<float*>(smem);
@@ -499,6 +510,12 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
       }
     }
   }
+#ifdef HP_TIMING
+  if (L >= 2048 && L < 2048 + 64 && (tid == 0 || tid == 256)) {
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    printf("blk %d row %d: prologue %llu  K loop %llu  epilogue %llu cycles\n", L, tid >> 8, hp_t1 - hp_t0, hp_t2 - hp_t1, t3 - hp_t2);
+  }
+#endif
 }
 
 // [Cout][3][3][Cin] bf16 (conv_igemm layout) -> [Cout / 256][Cin / 32][9][256 rows][4 slots][8] with the stage swizzle applied
