@@ -60,9 +60,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=96,
-                    help="query images per GPU per step (round 5: 96 -- 2 155-2 164 img/s vs 2 112-2 132 at 64 on one box: launch tails; "
-                         "activations stay below the 4-GiB range of the kernels' 32-bit offsets up to 112)")
+    ap.add_argument("--batch", type=int, default=120,
+                    help="query images per GPU per step (round 5: 120 -- on one box 2 112-2 132 img/s at 64, 2 228-2 233 at 96, 2 250-2 254 at 120: "
+                         "launch tails; the largest activation, res2's output, stays below the 4-GiB range of the kernels' 32-bit byte offsets "
+                         "up to 124 images -- beyond it the layers that read it fall back to slower kernels: 2 034 img/s at 128)")
     ap.add_argument("--ways", type=int, default=5)
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--height", type=int, default=800)
@@ -205,7 +206,7 @@ def main():
     sweep, fp32_img_s, parity, host_u8_img_s = None, None, None, None
     if rank == 0 and world == 1 and not args.no_sweep:
         sweep = {}
-        for b in (1, 8, 16, 64, 96):
+        for b in (1, 8, 16, 64, 96, 120):
             if b == B:
                 continue
             qs = queries[:b] if b <= B else dev_images(b, H, Wd, 7, device)

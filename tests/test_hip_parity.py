@@ -532,6 +532,45 @@ def test_full_size_properties_bf16(full_sd):
         assert (iou[same] <= 0.75).all()
 
 
+def test_full_size_batch120_far_end_of_the_tensors_bf16(full_sd):
+    """The default bench batch (120 images of 800x1333: activations of up to 4.13e9 bytes, just below the 4-GiB range of the
+    kernels' 32-bit byte offsets, 1.9 x the signed range).  Four distinct images repeated 30 times: every copy of an image must
+    come out the same wherever it sits in the batch -- up to bf16 rounding, not bit for bit: conv_hpipe / conv_pw start the K walk
+    of a tile at a half-slice that rotates with the tile index, so the fp32 summation order differs between
+    copies -- and equal its 4-image run (other tile shapes at B = 4) to the same tolerance."""
+    from sylph_amd import synthetic as W
+    base = W.synthetic_images(4, 800, 1333, seed=11)
+    codes = W.synthetic_codes(5, seed=4, scale=3.0)
+    eng = _engine("bf16", _cfg())
+    eng.load_state_dict(full_sd)
+    assert eng.preprocess([base[i % 4] for i in range(120)]) == (800, 1344)
+    eng.backbone()
+    pyr = eng.export_pyramid()
+    for lvl, p in enumerate(pyr):
+        assert torch.isfinite(p).all()
+        scale = p[0:4].abs().max().item()
+        for k in range(1, 30):
+            err = (p[0:4] - p[4 * k:4 * k + 4]).abs().max().item()
+            assert err <= 4e-2 * scale, f"level {lvl}: copy {k} differs from copy 0 by {err} (scale {scale})"
+    eng.head(codes["cls_conv"], codes["cls_bias"])
+    det = eng.decode()
+    assert len(det) == 120
+    for i in (4, 63, 116, 117, 118, 119):
+        a, b = det[i], det[i % 4]
+        assert abs(a["scores"].numel() - b["scores"].numel()) <= 5
+        n = min(20, a["scores"].numel(), b["scores"].numel())
+        assert n > 0 and (a["scores"][:n] - b["scores"][:n]).abs().max().item() <= 3e-2, f"image {i}: top scores differ from its copy {i % 4}"
+    small = [p[0:4].clone() for p in pyr]
+    del pyr
+    eng4 = _engine("bf16", _cfg())
+    eng4.load_state_dict(full_sd)
+    eng4.preprocess(base)
+    eng4.backbone()
+    for lvl, (a, b) in enumerate(zip(small, eng4.export_pyramid())):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() <= 4e-2 * scale, f"level {lvl}: batch-120 pyramid vs batch-4 pyramid"
+
+
 # --------------------------------------------------------------------------------- ROIEncoder (C5)
 def _roienc_cfg():
     cfg = _cfg(True)

@@ -10,7 +10,7 @@ timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trac
 python tools/rocpd_lds_conflicts.py $OUT/lds/l_results.db > $OUT/lds_bank_conflicts.txt
 python tools/rocpd_summary.py $OUT/trace/t_results.db $OUT/kernel_summary.md > /dev/null
 python tools/rocpd_timeline.py $OUT/trace/t_results.db > $OUT/timeline.txt
-python tools/rocpd_pmc.py $OUT/fetch/f_results.db $OUT/write/w_results.db 96 $OUT/pmc_hbm_traffic.json | tail -12
+python tools/rocpd_pmc.py $OUT/fetch/f_results.db $OUT/write/w_results.db 120 $OUT/pmc_hbm_traffic.json | tail -12
 head -30 $OUT/kernel_summary.md
 # batch-1 timeline (the serving shape of SylphPredictor / the reference's query loop)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_b1 -o t -- python bench.py --batch 1 --steps 20 --warmup 5 --inflight 1 --no-cpu-baseline --no-kernel-events --no-sweep --no-parity > $OUT/trace_b1.log 2>&1 || echo "b1 trace failed"
