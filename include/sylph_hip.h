@@ -25,7 +25,7 @@ extern "C" {
 
 typedef struct sylph_ctx sylph_ctx;
 
-enum { SYLPH_F32 = 0, SYLPH_BF16 = 1 };
+enum { SYLPH_F32 = 0, SYLPH_BF16 = 1, SYLPH_F32S = 2 };
 
 /* Subset of the yacs config the path reads (sylph/runner/adet_configs.py:25-61,
  * sylph/runner/default_configs.py:43-167). */
@@ -79,7 +79,10 @@ typedef struct sylph_config {
 /* Fill cfg with the defaults of the COCO Meta-FCOS finetune yaml. */
 void sylph_config_default(sylph_config* cfg);
 
-/* Context.  dtype = SYLPH_BF16 (bf16 storage + MFMA, fp32 accumulate) or SYLPH_F32 (parity mode). */
+/* Context.  dtype = SYLPH_BF16 (bf16 storage + MFMA, fp32 accumulate: the throughput mode), SYLPH_F32 (exact-fp32 MFMA: the reference
+ * arithmetic, fcos_outputs.py:904-1028 within 1e-3 with identical NMS indices) or SYLPH_F32S (the parity mode at speed: fp32 storage
+ * everywhere as in SYLPH_F32, every conv product as three bf16 MFMAs on operands split into bf16 hi + lo parts -- 2^-17 relative per
+ * operand, the same 1e-3 bound). */
 int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out);
 void sylph_ctx_destroy(sylph_ctx* ctx);
 const char* sylph_last_error(void);

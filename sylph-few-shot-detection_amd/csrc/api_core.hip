@@ -137,14 +137,14 @@ const char* sylph_last_error(void) { return g_err.c_str(); }
 
 int sylph_ctx_create(int device_id, int dtype, sylph_ctx** out) {
   if (!out) return fail("out is NULL");
-  if (dtype != SYLPH_F32 && dtype != SYLPH_BF16) return fail("dtype must be SYLPH_F32 or SYLPH_BF16");
+  if (dtype != SYLPH_F32 && dtype != SYLPH_BF16 && dtype != SYLPH_F32S) return fail("dtype must be SYLPH_F32, SYLPH_BF16 or SYLPH_F32S");
   int n = 0;
   HIPCHK(hipGetDeviceCount(&n));
   if (device_id < 0 || device_id >= n) return fail("no such HIP device: " + std::to_string(device_id));
   HIPCHK(hipSetDevice(device_id));
   sylph_ctx* c = new sylph_ctx();
   c->device = device_id;
-  c->dt = dtype == SYLPH_BF16 ? DT_BF16 : DT_F32;
+  c->dt = dtype == SYLPH_BF16 ? DT_BF16 : (dtype == SYLPH_F32S ? DT_F32S : DT_F32);
   sylph_config_default(&c->cfg);
   conv_set_nbuf(SYLPH_AB_ENV("SYLPH_CONV_NBUF", 1));  // A/B knob (-DSYLPH_ABLATE builds): LDS stages of the conv kernel
   if (const char* mp = getenv("SYLPH_MAX_PLANS")) c->max_plans = atoi(mp) > 1 ? (size_t)atoi(mp) : 2;

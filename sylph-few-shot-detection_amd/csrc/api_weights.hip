@@ -39,6 +39,21 @@ int pack_conv(sylph_ctx* c, const std::vector<const HostTensor*>& ws, ConvLayer*
     std::vector<uint16_t> h(packed.size());
     for (size_t i = 0; i < packed.size(); ++i) h[i] = f2bf_host(packed[i]);
     RET(upload(c, &L->w, h.data(), h.size() * 2));
+  } else if (c->dt == DT_F32S) {
+    // split-bf16 parity mode (conv_igemm.hip MmaSplit): every 32-element K-slice of a row becomes [32 bf16 hi | 32 bf16 lo], the same
+    // 128 bytes as its fp32 form; hi = bf16(w), lo = bf16(w - hi), both round-to-nearest-even
+    if (K % 32 != 0) return fail("split-bf16 mode: K = KH * KW * Cin must be a multiple of 32");
+    std::vector<uint16_t> h(packed.size() * 2);
+    for (size_t i = 0; i < packed.size(); ++i) {
+      const uint16_t hi = f2bf_host(packed[i]);
+      uint32_t hb = (uint32_t)hi << 16;
+      float hf;
+      memcpy(&hf, &hb, 4);
+      const size_t sl = i / 32, e = i % 32;
+      h[sl * 64 + e] = hi;
+      h[sl * 64 + 32 + e] = f2bf_host(packed[i] - hf);
+    }
+    RET(upload(c, &L->w, h.data(), h.size() * 2));
   } else {
     RET(upload(c, &L->w, packed.data(), packed.size() * 4));
   }

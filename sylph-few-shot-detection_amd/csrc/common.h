@@ -23,7 +23,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-enum DType { DT_F32 = 0, DT_BF16 = 1 };
+// DT_F32S: fp32 storage like DT_F32 (every kernel that only asks "bf16 or not" treats it as fp32); the convs split their operands into
+// bf16 hi + lo parts and run three bf16 MFMAs per product (conv_igemm.hip MmaSplit)
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F32S = 2 };
 
 // One segment of a convolution problem.  All *_row0 are row indices into the respective buffers.
 struct SegDesc {

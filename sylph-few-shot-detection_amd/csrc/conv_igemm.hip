@@ -81,6 +81,32 @@ template <> struct Mma<float> {
   }
 };
 
+// Split-bf16 parity mode (DT_F32S): fp32 activations and fp32-sized weights in HBM / LDS exactly as in the fp32 mode, but the products
+// run on the bf16 pipe at 3/16 of the fp32-MFMA cost.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest-even:
+// |x - hi - lo| <= 2^-18 |x|), and x * w ~ hi_x hi_w + hi_x lo_w + lo_x hi_w into the same fp32 accumulator (the dropped lo * lo term
+// is 2^-18 relative).  Activations are split in registers when a fragment is read (8 consecutive fp32 of one row = two ds_read_b128);
+// weights are split ONCE on the host: each 32-element K-slice of a packed row is stored as [32 bf16 hi | 32 bf16 lo] -- the same 128
+// bytes, so the staging code does not know the difference.
+struct MmaSplit {
+  static constexpr int KSTEPS = 2;  // 32 fp32 per slice / 16 per MFMA
+  static __device__ __forceinline__ void load_a(const char* tile, int row, int ks, int lane, bf16x8& hi, bf16x8& lo) {
+    const int c0 = ks * 4 + (lane >> 5) * 2, sw = (row >> 1) & 7;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(tile + row * 128 + ((c0 ^ sw) << 4));
+    const f32x4 q = *reinterpret_cast<const f32x4*>(tile + row * 128 + (((c0 + 1) ^ sw) << 4));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16_t hp = (bf16_t)p[e], hq = (bf16_t)q[e];
+      hi[e] = hp; hi[4 + e] = hq;
+      lo[e] = (bf16_t)(p[e] - (float)hp); lo[4 + e] = (bf16_t)(q[e] - (float)hq);
+    }
+  }
+  static __device__ __forceinline__ void load_w(const char* tile, int row, int ks, int lane, bf16x8& hi, bf16x8& lo) {
+    const int c = ks * 2 + (lane >> 5), sw = (row >> 1) & 7;
+    hi = *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ sw) << 4));
+    lo = *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((c + 4) ^ sw) << 4));
+  }
+};
+
 // Per-tile GroupNorm partial: every lane holds shifted sums over its rows of one 8-channel group; the RPP lanes of a
 // group are merged (Chan) in a fixed order by lane row 0 and written as (n, mean, M2).
 template <int RPP, int TPR>
@@ -108,8 +134,8 @@ __device__ __forceinline__ void gn_tile_reduce(float* red, int rr, int c8, float
   }
 }
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : (BM * BN >= 256 * 128 ? 2 : (BM * BN == 128 * 128 ? 4 : 1))))) void conv_igemm_kernel(const ConvArgs a) {
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO, bool SPLIT = false>
+__global__ __launch_bounds__(WGM * WGN * 64, (SPLIT ? (BM * BN == 128 * 128 ? 3 : (BM * BN == 128 * 64 && WGN == 2 ? 4 : 5)) : WGM * WGN == 8 ? 4 : (BM * BN <= 128 * 64 ? 5 : (BM * BN >= 256 * 128 ? 2 : (BM * BN == 128 * 128 ? 4 : 1))))) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // elements per 128-byte K-slice
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -125,6 +151,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   constexpr int HRND = (HALLOC + NT / 8 - 1) / (NT / 8);
   constexpr int STAGE = HALO ? (BN + HALLOC) * 128 : (BM + BN) * 128;
   static_assert(!HALO || (NBUF == 1 && BM == 128), "halo mode: 128-position patches, single stage");
+  static_assert(!SPLIT || (sizeof(T) == 4 && !HALO && !FAST), "split-bf16 mode: fp32 storage, generic epilogue");
   static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -347,6 +374,25 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
   auto compute = [&](int buf, int hoff) {
     const char* tA = HALO ? smem + BN * 128 : smem + buf * STAGE;
     const char* tB = HALO ? smem : tA + BM * 128;
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < MmaSplit::KSTEPS; ++ks) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) MmaSplit::load_a(tA, wm * WTM + i * 32 + (lane & 31), ks, lane, ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MmaSplit::load_w(tB, wn * WTN + j * 32 + (lane & 31), ks, lane, bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {  // the two cross terms first, the leading term last
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < Mma<T>::KSTEPS; ++ks) {
       typename Mma<T>::frag_t fa[TM], fb[TN];
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 ? 4 : (BM * BN <= 1
     gn_tile_reduce<RPP, TPR>(sC, rr, c8, gn_n, gn_pv, gn_s1, gn_s2, a.gn_partial + ((size_t)mt * (a.Cout >> 3) + (n0 >> 3)) * 3, active);
 }
 
-template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO = false>
+template <typename T, typename OutT, int BM, int BN, int WGM, int WGN, int NBUF, bool FAST, bool HALO = false, bool SPLIT = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int chunk = (a.n_mtiles + 7) / 8;
   const int grid = 8 * chunk * a.n_ntiles;
@@ -616,8 +662,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t s) {
   size_t lds = stage > epi ? stage : epi;
   if (a.res_lds) lds += (size_t)BM * BN * sizeof(T);
   if (!(stage >= epi + (size_t)BN * 8)) lds += (size_t)BN * 8;  // scale/shift parked behind everything else
-  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = conv_igemm_kernel<T, OutT, BM, BN, WGM, WGN, NBUF, FAST, HALO, SPLIT>;
   hipLaunchKernelGGL(kern, dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(WGM * WGN * 64), lds, s, a);
   return (int)hipGetLastError();
 }
@@ -772,6 +818,14 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
     }
     if (!out_f32 && g_nbuf == 1 && fast_ok(a, BN)) return launch_n<bf16_t, bf16_t, 1, true>(a, BM, BN, s);
     return out_f32 ? launch_t<bf16_t, float>(a, BM, BN, s) : launch_t<bf16_t, bf16_t>(a, BM, BN, s);
+  }
+  if (dt == DT_F32S) {  // split-bf16 parity mode: fp32 storage, three bf16 MFMAs per product (MmaSplit)
+    if (BM == 128 && BN == 128) return launch_cfg<float, float, 128, 128, 2, 2, 1, false, false, true>(a, s);
+    if (BM == 128 && BN == 64) return launch_cfg<float, float, 128, 64, 2, 2, 1, false, false, true>(a, s);
+    if (BM == 128 && BN == 32) return launch_cfg<float, float, 128, 32, 4, 1, 1, false, false, true>(a, s);
+    if (BM == 64 && BN == 128) return launch_cfg<float, float, 64, 128, 2, 2, 1, false, false, true>(a, s);
+    if (BM == 64 && BN == 64) return launch_cfg<float, float, 64, 64, 2, 2, 1, false, false, true>(a, s);
+    return -1;
   }
   return launch_t<float, float>(a, BM, BN, s);
 }

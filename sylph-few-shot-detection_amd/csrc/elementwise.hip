@@ -539,9 +539,23 @@ __global__ void pack_codes_kernel(const float* __restrict__ w, int N, int C, int
   out[i] = Cvt<T>::from_f(n < N ? w[i] : 0.f);
 }
 
+// the same for the split-bf16 parity mode: every 32-element K-slice as [32 bf16 hi | 32 bf16 lo] (conv_igemm.hip MmaSplit)
+__global__ void pack_codes_split_kernel(const float* __restrict__ w, int N, int C, int Npad, bf16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad * C) return;
+  const float v = i / C < N ? w[i] : 0.f;
+  const bf16_t hi = (bf16_t)v;
+  const size_t o = (size_t)(i >> 5) * 64 + (i & 31);  // C % 32 == 0: slices do not straddle rows
+  out[o] = hi;
+  out[o + 32] = (bf16_t)(v - (float)hi);
+}
+
 int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, hipStream_t s) {
   dim3 grid((Npad * C + 255) / 256), block(256);
-  if (dt == DT_BF16)
+  if (dt == DT_F32S) {
+    if (C % 32 != 0) return -1;
+    hipLaunchKernelGGL(pack_codes_split_kernel, grid, block, 0, s, w, N, C, Npad, (bf16_t*)out);
+  } else if (dt == DT_BF16)
     hipLaunchKernelGGL(pack_codes_kernel<bf16_t>, grid, block, 0, s, w, N, C, Npad, (bf16_t*)out);
   else
     hipLaunchKernelGGL(pack_codes_kernel<float>, grid, block, 0, s, w, N, C, Npad, (float*)out);

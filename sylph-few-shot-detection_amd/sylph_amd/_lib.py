@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SYLPH_LIB_PATH") or os.path.join(os.path.dirname(_HER
 
 SYLPH_F32 = 0
 SYLPH_BF16 = 1
+SYLPH_F32S = 2
 
 
 class SylphConfig(Structure):

@@ -169,7 +169,7 @@ class Engine:
         self.device = torch.device("cuda", device)
         self.dtype = dtype
         self._ctx = c_void_p(0)
-        dt = {"bf16": _lib.SYLPH_BF16, "f32": _lib.SYLPH_F32, "fp32": _lib.SYLPH_F32}[dtype]
+        dt = {"bf16": _lib.SYLPH_BF16, "f32": _lib.SYLPH_F32, "fp32": _lib.SYLPH_F32, "f32s": _lib.SYLPH_F32S}[dtype]
         check(self.L.sylph_ctx_create(device, dt, ctypes.byref(self._ctx)), "ctx_create")
         self.sc = config_from_cfg(cfg)
         if cand_cap:

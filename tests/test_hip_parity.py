@@ -12,7 +12,15 @@ pytestmark = pytest.mark.gpu
 
 def _engine(dtype, cfg=None, **kw):
     from sylph_amd.engine import Engine
+    if dtype == "f32":  # tests/test_split_mode_gpu.py re-runs the fp32 checks of this file in the split-bf16 parity mode ("f32s")
+        dtype = os.environ.get("SYLPH_TEST_F32_MODE", "f32")
     return Engine(cfg, dtype=dtype, **kw)
+
+
+def _f32_tol(exact, split):
+    """Tolerance of an op-level fp32 check: `exact` for the fp32-MFMA mode, `split` when the file runs in the split-bf16 mode (each
+    operand carries 16 mantissa bits: 2^-17 relative per product)."""
+    return split if os.environ.get("SYLPH_TEST_F32_MODE", "f32") == "f32s" else exact
 
 
 def _bf16_round(t):
@@ -77,7 +85,7 @@ def test_conv2d_matches_torch(dtype, case):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    tol = 2e-5 if dtype == "f32" else 2e-2
+    tol = _f32_tol(2e-5, 6e-5) if dtype == "f32" else 2e-2
     err = (y - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), f"max err {err}"
 
@@ -444,10 +452,27 @@ def test_full_episode_matches_oracle_f32(full_sd):
     assert sum(w["scores"].numel() for w in want) > 20
     for wv, gv in zip(want, got):
         assert gv["scores"].numel() == wv["scores"].numel()
-        np.testing.assert_array_equal(gv["cand_index"].cpu().numpy(), _cand_ordinals(wv, 128, 160, 5))
-        np.testing.assert_allclose(gv["scores"].cpu().numpy(), wv["scores"].numpy(), atol=1e-3)
-        _assert_boxes(gv["pred_boxes"].cpu().numpy(), wv["pred_boxes"].numpy(), wv["fpn_levels"].numpy())
-        np.testing.assert_array_equal(gv["pred_classes"].cpu().numpy(), wv["pred_classes"].numpy())
+        perm = _same_candidates(gv["cand_index"].cpu().numpy(), _cand_ordinals(wv, 128, 160, 5), wv["scores"].numpy())
+        np.testing.assert_allclose(gv["scores"].cpu().numpy(), wv["scores"].numpy()[perm], atol=1e-3)
+        _assert_boxes(gv["pred_boxes"].cpu().numpy(), wv["pred_boxes"].numpy()[perm], wv["fpn_levels"].numpy()[perm])
+        np.testing.assert_array_equal(gv["pred_classes"].cpu().numpy(), wv["pred_classes"].numpy()[perm])
+
+
+def _same_candidates(got_ord, want_ord, want_scores):
+    """The kept (level, location, class) candidates, in order.  Exact-fp32 mode: identical arrays.  Split-bf16 mode (2^-17 relative per
+    product instead of 2^-24): the same SET, and two candidates may trade places only if the oracle's own scores for them are within 1e-4
+    of each other (a tie at the mode's resolution; the sort is by score).  -> for each HIP detection its position in the oracle's list."""
+    if np.array_equal(got_ord, want_ord):
+        return np.arange(want_ord.size)
+    assert os.environ.get("SYLPH_TEST_F32_MODE", "f32") == "f32s", (got_ord, want_ord)
+    assert got_ord.size == want_ord.size and np.array_equal(np.sort(got_ord), np.sort(want_ord)), "different candidate sets"
+    pos = {int(o): k for k, o in enumerate(want_ord.tolist())}
+    perm = np.array([pos[int(o)] for o in got_ord.tolist()])
+    moved = np.nonzero(perm != np.arange(perm.size))[0]
+    gap = np.abs(want_scores[perm[moved]] - want_scores[moved]).max()
+    print(f"split mode: {moved.size} candidates trade places, oracle scores within {gap:.2e}")
+    assert gap <= 1e-4, gap
+    return perm
 
 
 def _keys_of_ordinals(ords, H, W, N):
