@@ -84,6 +84,17 @@ def main():
     ap.add_argument("--dump-codes", default=None, help="rank 0 writes the gathered, normalised class codes (N x 257) to this .pt file (tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,7 +228,7 @@ def main():
             for _ in range(5):  # the reference excludes 5 warm-up iterations (meta_learn_evaluation.py:392-417)
                 step_b()
             torch.cuda.synchronize()
-            n = 20 if b == 1 else 6
+            n = 40 if b == 1 else (24 if b <= 16 else 6)  # small batches: enough steps that rounds can be compared (a step is 1.6 - 9 ms there)
             ts = time.perf_counter()
             for _ in range(n):
                 step_b()  # synchronous: decode() ends on the count read-back, as the reference loop ends on cuda.synchronize

@@ -62,11 +62,17 @@ void set_patch(SegDesc* s, int ph, int pw, int xpad) {
   s->inv_hw2 = (65536u + s->hpitch - 1) / s->hpitch;
 }
 
-// 3x3 s1 p1 halo modes: M tiles are ph x pw patches of one segment, tile.y = (row << 16) | col.  `pair`: the tile list is
-// padded to an even length with an empty patch (conv_halo_pipe.hip works on two patches per block).
-int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g) {
+// 3x3 s1 p1 halo modes: M tiles are ph x pw patches of one segment, tile.y = (row << 16) | col.  `pair` (conv_hpipe.hip works on two
+// patches per block): the patch list of every IMAGE (`group` consecutive segments) is padded to an even length with an empty patch, so a
+// pair never straddles two images, and the first tile of a pair carries the pair's index INSIDE its image in tile.x >> 20 (the kernel's
+// K-walk rotation key; tile.x & 0xfffff = segment): an image's results do not depend on where in the batch it sits.  Images that would
+// grow by more than 1/8 (one-patch ROI maps) keep the flat pairing.
+int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g, int group) {
   std::vector<int2> tiles;
   static const int fixed = SYLPH_AB_ENV("SYLPH_CONV_PATCH_8X16", 0);  // A/B knob (-DSYLPH_ABLATE builds): the round-1 geometry
+  if (group < 1 || segs.size() % (size_t)group != 0) group = 1;
+  size_t g0 = 0;  // first tile of the current image
+  bool per_image = pair && segs.size() < (1u << 20);
   for (size_t s = 0; s < segs.size(); ++s) {
     int ph, pw;
     if (fixed) { ph = max_pos / 16; pw = 16; }
@@ -76,9 +82,18 @@ int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int ha
     for (int y = 0; y < segs[s].out_H; y += ph)
       for (int x = 0; x < segs[s].out_W; x += pw) tiles.push_back(make_int2((int)s, (y << 16) | x));
     g->seg_tiles.push_back(make_int2(t0, (int)tiles.size() - t0));
+    if (per_image && (s + 1) % (size_t)group == 0) {
+      const size_t n = tiles.size() - g0;
+      if ((n & 1) && n < 8) per_image = false;  // (every image has the same shape: decided on the first one)
+      if (per_image) {
+        if (n & 1) tiles.push_back(make_int2(0, 0x7fff << 16));  // origin below every map: nothing loaded, nothing stored
+        for (size_t t = g0; t < tiles.size(); t += 2) tiles[t].x |= (int)((((t - g0) >> 1) & 0x7ff) << 20);
+      }
+      g0 = tiles.size();
+    }
   }
+  if (pair && (tiles.size() & 1)) tiles.push_back(make_int2(0, 0x7fff << 16));
   g->n_mtiles = (int)tiles.size();
-  if (pair && (tiles.size() & 1)) tiles.push_back(make_int2(0, 0x7fff << 16));  // origin below every map: nothing loaded, nothing stored
   void *ds = nullptr, *dtl = nullptr;
   RET(upload(c, &ds, segs.data(), segs.size() * sizeof(SegDesc)));
   RET(upload(c, &dtl, tiles.data(), tiles.size() * sizeof(int2)));
@@ -213,7 +228,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     if (pw) { BM = bm; BN = bn; }
   }
   Geom g;
-  if (hpipe) RET(make_geom_patch(c, segs, 128, 256, 4, true, &g));
+  if (hpipe) RET(make_geom_patch(c, segs, 128, 256, 4, true, &g, o.segs_per_image));
   else if (halo) RET(make_geom_patch(c, segs, 128, 184, 2, false, &g));
   else RET(make_geom(c, segs, BM, &g));
   ConvArgs a;
@@ -234,18 +249,26 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   }
   if (pw) {  // stage-image weight layout + scale/shift table of conv_pw.hip, packed once per layer; one descriptor per M tile
     auto it = c->pw_weights.find(L.w);
+    if (it != c->pw_weights.end() && !spw && !it->second.first) {  // first packed for conv_spw (table only): add the stage images
+      OwnerScope ctx_owned(c, nullptr);
+      RET(c->dalloc(&it->second.first, (size_t)L.Cout * L.Cin * 2));
+      KCHK(launch_pw_pack_weights(L.w, it->second.first, L.Cout, L.Cin, BN, c->stream), "pw_pack_weights");
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (it == c->pw_weights.end()) {
       void* wp = nullptr;
       float* tb = nullptr;
       OwnerScope ctx_owned(c, nullptr);
-      RET(c->dalloc(&wp, (size_t)L.Cout * L.Cin * 2));
       RET(c->dalloc((void**)&tb, (size_t)2 * L.Cout * sizeof(float)));
-      KCHK(launch_pw_pack_weights(L.w, wp, L.Cout, L.Cin, BN, c->stream), "pw_pack_weights");
+      if (!spw) {  // conv_spw reads the conv_igemm layout itself (weights in registers): no stage-image copy (7 MB of dead memory)
+        RET(c->dalloc(&wp, (size_t)L.Cout * L.Cin * 2));
+        KCHK(launch_pw_pack_weights(L.w, wp, L.Cout, L.Cin, BN, c->stream), "pw_pack_weights");
+      }
       KCHK(launch_pw_pack_table(L.scale, L.shift, tb, L.Cout, BN, c->stream), "pw_pack_table");
       HIPCHK(hipStreamSynchronize(c->stream));
       it = c->pw_weights.emplace(L.w, std::make_pair(wp, tb)).first;
     }
-    if (!spw) a.wt = it->second.first;  // conv_spw reads the conv_igemm layout itself (weights in registers)
+    if (!spw) a.wt = it->second.first;
     a.pw_table = it->second.second;
     if (!c->pw_trash) {
       OwnerScope ctx_owned(c, nullptr);

@@ -71,7 +71,7 @@ int build_head(sylph_ctx* c, Plan* P) {
     void* out = b0;
     if (!tower_gn) {  // no norm layer: the ReLU is the conv epilogue's
       for (size_t i = 0; i < convs.size(); ++i) {
-        ConvOpts o; o.pad = 1; o.relu_nch = 1 << 30;
+        ConvOpts o; o.pad = 1; o.segs_per_image = c->cfg.nlevels; o.relu_nch = 1 << 30;
         RET(add_conv(c, ops, convs[i], in, 256, out, 256, segs, o));
         if (which < 2) { P->tap_out[which].push_back(out); P->tap_coef[which].push_back(nullptr); }
         in = out;
@@ -89,7 +89,7 @@ int build_head(sylph_ctx* c, Plan* P) {
     const bool fuse = gn_fuse_on && convs.size() > 1 && convs[0].Cin <= 512 && use_hpipe(c, convs[1], segs, probe);
     const float2* coef_prev = nullptr;
     for (size_t i = 0; i < convs.size(); ++i) {
-      ConvOpts o; o.pad = 1;
+      ConvOpts o; o.pad = 1; o.segs_per_image = c->cfg.nlevels;
       if (coef_prev) { o.gn_coef = coef_prev; o.gn_relu = 1; }
       const float2* coef = nullptr;
       const bool is_last = i + 1 == convs.size();
@@ -126,7 +126,7 @@ int build_head(sylph_ctx* c, Plan* P) {
       int in_ld = 256;
       void* out = P->tA;
       for (size_t i = 0; i < c->pair_tower.size(); ++i) {
-        ConvOpts o; o.pad = 1;
+        ConvOpts o; o.pad = 1; o.segs_per_image = c->cfg.nlevels;
         if (i > 0) { o.group_cout = 256; o.group_in_off = 256; }
         RET(add_conv_gn(c, ops, c->pair_tower[i], in, in_ld, out, csegs, o, c->pair_gn[i], 1));
         in = out; in_ld = 512;
@@ -194,7 +194,7 @@ int build_head(sylph_ctx* c, Plan* P) {
       return timed_op(c, "gn_taps_kernel+tap_gather_kernel", fl, s, [=](hipStream_t st) { return launch_gn_pred_taps(xin, 256, bc, wt, cp, bias, 4, 4, taps_ws, plane_rows, pout, 8, sgd, tld, ntl, st); });
     });
   } else {
-    ConvOpts op; op.pad = 1; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
+    ConvOpts op; op.pad = 1; op.segs_per_image = c->cfg.nlevels; op.relu_nch = 4; op.mul_nch = 4; op.out_f32 = true;
     RET(add_conv(c, ops, c->pred, box_feat, feat_ld, P->pred, 8, segs, op));
   }
   c->build_slot = 0;
@@ -441,7 +441,7 @@ int sylph_fcos_head_pretrained(sylph_ctx* c, int* num_classes) {
   if (c->cls_logits.Cout_pad != P->logits_ld) return fail("internal: cls_logits padding");
   if (P->cls_logits_dst != P->logits) {  // (re)build the conv launch for this plan's buffers
     P->cls_logits_ops.clear();
-    ConvOpts o; o.pad = c->cls_logits.KH / 2; o.out_f32 = true;
+    ConvOpts o; o.pad = c->cls_logits.KH / 2; o.segs_per_image = c->cfg.nlevels; o.out_f32 = true;
     RET(add_conv(c, P->cls_logits_ops, c->cls_logits, P->cls_feat, P->cls_ld, P->logits, P->logits_ld, pyramid_segs(c, P), o));
     P->cls_logits_dst = P->logits;
   }

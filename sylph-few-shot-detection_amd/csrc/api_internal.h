@@ -280,6 +280,7 @@ struct ConvOpts {
   double flops = -1.0;     // algorithmic FLOPs of the launch when they differ from 2*M*N*K (stem padding)
   const float2* gn_coef = nullptr;  // fused GroupNorm(+ReLU) of the INPUT (conv_hpipe.hip): (a, b) per (segment, input channel)
   int gn_relu = 0;
+  int segs_per_image = 1;  // consecutive segments that belong to one image (pyramid-wide launches: the FPN levels)
   int stream_slot = 0;     // 1: the op will run on the context's side stream (its split-K scratch must not be the main stream's)
 };
 
@@ -311,7 +312,7 @@ void level_dims(const sylph_config& cfg, int H, int W, int* hl, int* wl, int* of
 int make_geom(sylph_ctx* c, const std::vector<SegDesc>& segs, int BM, Geom* g);
 void pick_patch(int H, int W, int max_pos, int halo_rows, int xpad, int* ph_out, int* pw_out);
 void set_patch(SegDesc* s, int ph, int pw, int xpad);
-int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g);
+int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g, int group = 1);
 long patch_count(const std::vector<SegDesc>& segs, int max_pos, int halo_rows, int xpad);
 int timed_conv(sylph_ctx* c, DType dt, bool of32, const ConvArgs& a, int BM, int BN, double flops, hipStream_t s);
 int timed_op(sylph_ctx* c, const char* kern, double flops, hipStream_t s, const std::function<int(hipStream_t)>& fn);

@@ -821,19 +821,12 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
 
 // small != 0: the double-buffered 64-position variant (the tile table must hold patches of <= 64 positions with <= 128 halo rows)
 int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
-  static bool attr_set = false;
-  static int ncu = 256;
   constexpr int lds_stage = 4 * 4096 + 512;  // store staging + position table
   constexpr int lds_big = 192 * 512 + 192 * TP + (4 * MID + 2 * C) * 4 + lds_stage;
   static_assert(lds_big == LDS_BYTES + lds_stage && lds_big <= 160 * 1024, "LDS budget");
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)bottleneck64_kernel<3, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big) != hipSuccess) return -7;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;
+  const int dev = current_device(), ncu = device_cu_count(dev);
+  if (!once.run(dev, [] { return hipFuncSetAttribute((const void*)bottleneck64_kernel<3, 2, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big) == hipSuccess; })) return -7;
   // the tile walk pairs blockIdx & 7 (XCD) with blockIdx >> 3: the grid must be a whole number of 8-block rounds
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
@@ -843,16 +836,9 @@ int launch_bottleneck64(const BottleneckArgs& a, int small, hipStream_t s) {
 }
 
 int launch_bottleneck64p(const BottleneckArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  static int ncu = 256;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)bottleneck64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES) != hipSuccess) return -7;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;
+  const int dev = current_device(), ncu = device_cu_count(dev);
+  if (!once.run(dev, [] { return hipFuncSetAttribute((const void*)bottleneck64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES) == hipSuccess; })) return -7;
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
   hipLaunchKernelGGL(bottleneck64p_kernel, dim3(grid), dim3(256), PLDS_BYTES, s, a);

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 // A/B knobs of variants that were measured and rejected exist only in builds made with -DSYLPH_ABLATE
 // (tools/build_variant.sh): the product library reads no environment for them and carries no instantiation of them.
 #ifdef SYLPH_ABLATE
@@ -141,6 +143,33 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+
+// Per-device launch set-up of the persistent kernels (function-local statics took the CU count and the LDS attribute from
+// whichever device launched first, unsynchronised).  Both are keyed by the CURRENT device; racing threads at worst repeat an idempotent call.
+inline int current_device() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? dev : 0;
+}
+inline int device_cu_count(int dev) {
+  static std::atomic<int> cus[64];
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t p;
+    n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+struct PerDeviceOnce {  // `static PerDeviceOnce once;  if (!once.run(dev, [&] { return hipFuncSetAttribute(...) == hipSuccess; })) return -7;`
+  std::atomic<unsigned long long> done{0};
+  template <typename F> bool run(int dev, F&& f) {
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (!f()) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+  }
+};
 
 // ---- launcher prototypes (one per translation unit) -----------------------------------------
 // conv_igemm.hip

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  const int2 tl0 = a.tiles[2 * mt], tl1 = a.tiles[2 * mt + 1];
+  int2 tl0 = a.tiles[2 * mt], tl1 = a.tiles[2 * mt + 1];
+  const int rot_key = (int)((unsigned)tl0.x >> 20);  // index of this pair inside its image (api_conv.hip make_geom_patch)
+  tl0.x &= 0xfffff;
   const SegDesc sd0 = a.segs[tl0.x], sd1 = a.segs[tl1.x];
 
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
@@ -134,8 +136,9 @@ __global__ __launch_bounds__(PNT, 1) void conv_hpipe_kernel(const ConvArgs a) {
   const int Cin = a.Cin;
   const int ncc = Cin >> 5;  // 32-channel half-slices
   const int goff = a.group_cout > 0 ? ((nt * 256) / a.group_cout) * a.group_in_off : 0;
-  // K-loop rotation: this block walks the half-slices c0, c0+1, ... (mod ncc)
-  const int c0 = (mt + nt) % ncc;
+  // K-loop rotation: this block walks the half-slices c0, c0+1, ... (mod ncc); keyed on the pair's place inside its own image, so the
+  // summation order of an image's outputs does not depend on the batch around it
+  const int c0 = (rot_key + nt) % ncc;
 
   // ---- loader state --------------------------------------------------------------------------------------------
   // lane (r4, s4) of a block-wide global_load_lds fetches 16-byte slot s4 of LDS row (round * 128 + r4)

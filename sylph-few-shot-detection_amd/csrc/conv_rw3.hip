@@ -376,16 +376,9 @@ bool conv_rw3_patch_ok(int ph, int pw) {
 }
 
 int launch_conv_rw3(const BottleneckArgs& a, hipStream_t s) {
-  static bool attr_set = false;
-  static int ncu = 256;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_rw3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RW_LDS) != hipSuccess) return -7;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;
+  const int dev = current_device(), ncu = device_cu_count(dev);
+  if (!once.run(dev, [] { return hipFuncSetAttribute((const void*)conv_rw3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RW_LDS) == hipSuccess; })) return -7;
   const int want = (a.n_tiles + 7) & ~7;
   const int grid = want < ncu ? want : (ncu & ~7);
   hipLaunchKernelGGL(conv_rw3_kernel, dim3(grid), dim3(256), RW_LDS, s, a);

@@ -348,12 +348,12 @@ bool conv_spw_ok(DType dt, bool out_f32, const ConvArgs& a) {
 
 template <int K>
 static int launch_spw_k(const ConvArgs& a, int grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)conv_spw_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) != hipSuccess) return -7;
-    if (hipFuncSetAttribute((const void*)conv_spw_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) != hipSuccess) return -7;
-    attr = true;
-  }
+  static PerDeviceOnce once;
+  if (!once.run(current_device(), [] {
+        return hipFuncSetAttribute((const void*)conv_spw_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_spw_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) == hipSuccess;
+      }))
+    return -7;
   if (a.relu_nch > 0) hipLaunchKernelGGL((conv_spw_kernel<K, true>), dim3(grid), dim3(512), SPW_LDS, s, a);
   else hipLaunchKernelGGL((conv_spw_kernel<K, false>), dim3(grid), dim3(512), SPW_LDS, s, a);
   return (int)hipGetLastError();
@@ -361,13 +361,7 @@ static int launch_spw_k(const ConvArgs& a, int grid, hipStream_t s) {
 
 // a.wt: the layer's weights in the conv_igemm layout [Cout][K] (read once per block into registers); a.pw_table, a.pw_desc as conv_pw
 int launch_conv_spw(const ConvArgs& a, hipStream_t s) {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return -7;
-    n_cu = p.multiProcessorCount;
-  }
+  const int n_cu = device_cu_count(current_device());
   // blocks of an XCD = (M stride) x (N tiles): a multiple of 8 * n_ntiles, at most one block per CU
   const int per = 8 * a.n_ntiles;
   int grid = (n_cu / per) * per;

@@ -117,6 +117,7 @@ def fit_block(local: torch.Tensor, capacity: int) -> torch.Tensor:
     exception here would leave the other ranks blocked in it.  The number of dropped rows travels in the overflow lane of
     the block's first row; `check_overflow` turns it into the same error on every rank once the gathered rows are on the host."""
     n = int(local.shape[0])
+    capacity = max(int(capacity), 1)  # a block of zero rows could not carry the overflow lane (ADVICE r5); gather_packed_codes clamps alike
     if n <= capacity:
         return local
     local = local[:capacity].clone()
@@ -138,6 +139,7 @@ def check_overflow(host_rows: torch.Tensor, capacity: Optional[int] = None):
 
 def pad_block(local: torch.Tensor, capacity: int) -> torch.Tensor:
     """(n, ROW) -> (capacity, ROW), unused rows zero (valid = 0); n > capacity: see fit_block."""
+    capacity = max(int(capacity), 1)
     local = fit_block(local, capacity)
     if local.shape[0] == capacity:
         return local.contiguous()
@@ -215,7 +217,7 @@ def gather_packed_codes(local: torch.Tensor, capacity: Optional[int] = None) -> 
     host read-back; consumers select by the valid column).  capacity defaults to the local row count, which is only
     correct when every rank holds the same number of rows.  A rank with more rows than `capacity` does not raise here (the others
     would hang in the collective): see fit_block / check_overflow."""
-    cap = int(capacity) if capacity is not None else max(int(local.shape[0]), 1)
+    cap = max(int(capacity), 1) if capacity is not None else max(int(local.shape[0]), 1)  # same clamp on every rank
     if _c_abi_gather is not None and local.is_cuda:
         return _c_abi_gather.gather(fit_block(local, cap), cap)  # pads inside the call (memset of the block tail on the stream)
     return gather_code_blocks(pad_block(local, cap))

@@ -37,6 +37,26 @@ def config_from_cfg(cfg) -> SylphConfig:
     sc.num_share_convs = int(f.NUM_SHARE_CONVS)
     if bool(f.USE_DEFORMABLE):
         raise NotImplementedError("MODEL.FCOS.USE_DEFORMABLE is not supported")
+    # backbone branches the five target configs leave at their defaults: refuse them instead of silently building the default graph
+    r = m.RESNETS
+    if int(r.get("NUM_GROUPS", 1)) != 1 or int(r.get("WIDTH_PER_GROUP", 64)) != 64:
+        raise NotImplementedError("MODEL.RESNETS.NUM_GROUPS / WIDTH_PER_GROUP: only the plain ResNet bottleneck (1 group x 64) is supported (no ResNeXt)")
+    if any(bool(v) for v in r.get("DEFORM_ON_PER_STAGE", [False] * 4)):
+        raise NotImplementedError("MODEL.RESNETS.DEFORM_ON_PER_STAGE: deformable bottleneck convs are not supported")
+    if int(r.get("RES5_DILATION", 1)) != 1:
+        raise NotImplementedError("MODEL.RESNETS.RES5_DILATION != 1 is not supported")
+    if int(r.get("RES2_OUT_CHANNELS", 256)) != 256 or int(r.get("STEM_OUT_CHANNELS", 64)) != 64:
+        raise NotImplementedError("MODEL.RESNETS.RES2_OUT_CHANNELS / STEM_OUT_CHANNELS: only 256 / 64 are supported")
+    if str(r.get("NORM", "FrozenBN")) != "FrozenBN":
+        raise NotImplementedError(f"MODEL.RESNETS.NORM {r.NORM!r}: only FrozenBN (inference) is supported")
+    fpn = m.get("FPN", None)
+    if fpn is not None:
+        if str(fpn.get("FUSE_TYPE", "sum")) != "sum":
+            raise NotImplementedError(f"MODEL.FPN.FUSE_TYPE {fpn.FUSE_TYPE!r}: only 'sum' is supported")
+        if str(fpn.get("NORM", "") or "") != "":
+            raise NotImplementedError(f"MODEL.FPN.NORM {fpn.NORM!r}: only '' (bias convs) is supported")
+        if int(fpn.get("OUT_CHANNELS", 256)) != 256:
+            raise NotImplementedError("MODEL.FPN.OUT_CHANNELS: only 256 is supported")
     norm = "" if f.NORM is None else str(f.NORM)
     if norm in ("GN", "NaiveGN"):  # adet's NaiveGroupNorm computes GroupNorm(32, C) by hand: the same arithmetic
         sc.tower_norm = 0

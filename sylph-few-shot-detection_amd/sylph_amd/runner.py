@@ -132,6 +132,7 @@ class MetaFCOSRunner:
                 cap = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
                 dist.all_reduce(cap, op=dist.ReduceOp.MAX)
                 capacity = max(int(cap.item()), 1)
+            capacity = max(int(capacity), 1)  # as gather_packed_codes / fit_block clamp it: a zero-row block cannot carry the overflow flag
             rows = D.gather_packed_codes(local, capacity).cpu()
             D.check_overflow(rows, capacity)  # same decision on every rank, after the collective
             # "acc_weight" comes back on exactly the records that carried it (explicit flag lane): nothing is inferred from values

@@ -1,6 +1,9 @@
 """Parity of the conv kernel variants that the small golden shapes do not select by themselves: the halo-tile
 mode of conv_igemm (picked only when its patches waste < 50 % of a launch) and conv_hpipe_kernel.
 
+The forced-variant reruns select the bf16 tests of tests/test_hip_parity.py that can reach the forced kernel (the variants exist in
+bf16 mode only; the fp32 / split-bf16 checks of that file are untouched by the knobs and run once, in the main suite).
+
 conv_hpipe_kernel (256x256 deep-pipelined halo conv, two patches per block) is picked automatically only for
 launches with >= 512 blocks, so: (1) convs large enough to select it are compared with torch (map sizes that give
 ragged patches, odd patch counts, Cout 256 and 512), and (2) the head / episode parity tests are re-run in a
@@ -46,14 +49,14 @@ def _rerun(env_extra, k=None):
 
 
 def test_parity_suite_with_hpipe_kernel_forced():
-    _rerun({"SYLPH_CONV_HPIPE": "2"}, "conv2d or head or episode or backbone or codegen or full or roi_encoder")
+    _rerun({"SYLPH_CONV_HPIPE": "2"}, "bf16 and (conv2d or head or episode or backbone_fpn or codegen_tower or c3_full_size or full_size_prop)")
 
 
 def test_parity_suite_with_halo_mode_forced():
     """SYLPH_CONV_HALO=2 selects the halo-tile mode for every eligible 3x3 stride-1 conv whatever the patch waste
     (SYLPH_CONV_HPIPE=0 keeps the 256-wide layers on it too): conv2d vs torch, head / decode / codegen goldens,
     backbone and episode vs the oracle all run through it."""
-    _rerun({"SYLPH_CONV_HALO": "2", "SYLPH_CONV_HPIPE": "0"})
+    _rerun({"SYLPH_CONV_HALO": "2", "SYLPH_CONV_HPIPE": "0"}, "bf16 and (conv2d or head or episode or backbone_fpn or codegen or c3_full_size or full_size_prop)")
 
 
 def test_parity_suite_with_streaming_residual_conv_everywhere():
@@ -62,9 +65,9 @@ def test_parity_suite_with_streaming_residual_conv_everywhere():
     ragged batches, partial last tiles, launches of a few tiles: conv2d vs torch, backbone / episode / full-size checks against the
     oracle, and the ulp-level block tests."""
     env = {"SYLPH_CONV_SPW": "2"}
-    _rerun(env, "conv2d or backbone or episode or c3 or full_size")
+    _rerun(env, "bf16 and (conv2d or backbone_fpn or c3_full_size or full_size_prop)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "bottleneck or stage"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                        "bottleneck"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
@@ -73,9 +76,9 @@ def test_parity_suite_with_register_weight_conv2_everywhere():
     conv_rw3_kernel whatever the launch size -- launches of a few patches, fewer patches than CUs, one-patch images: backbone / episode /
     full-size checks against the oracle and the ulp-level block tests."""
     env = {"SYLPH_CONV_RW3": "2"}
-    _rerun(env, "backbone or episode or bottleneck or full_size")
+    _rerun(env, "bf16 and (backbone_fpn or c3_full_size or full_size_prop)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "bottleneck or stage"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                        "bottleneck"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
@@ -85,7 +88,7 @@ def test_parity_suite_with_pointwise_kernel_everywhere():
     torch, backbone / episode / full-size checks, and the ulp-level block tests.  (The rejected 128x128 / 256x256 tile variants
     exist only in -DSYLPH_ABLATE builds, tools/build_variant.sh.)"""
     env = {"SYLPH_CONV_PW": "2"}
-    _rerun(env, "conv2d or backbone or episode or c3 or full_size_prop")
+    _rerun(env, "bf16 and (conv2d or backbone_fpn or c3_full_size or full_size_prop)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
                         "bottleneck"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -96,9 +99,9 @@ def test_parity_suite_with_split_k_and_two_streams_forced():
     tile count or depth -- 1x1 and 3x3, with and without a same-geometry residual, strided -- and SYLPH_HEAD_STREAMS=2 always runs the
     bbox tower on the second stream: conv2d vs torch, backbone / episode vs the oracle, the full-size and the ulp-level block tests."""
     env = {"SYLPH_SPLIT_K": "2", "SYLPH_HEAD_STREAMS": "2"}
-    _rerun(env, "conv2d or backbone or episode or c3 or full_size_prop or head")
+    _rerun(env, "bf16 and (conv2d or backbone_fpn or c3_full_size or full_size_prop or head)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "bottleneck or detections"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                        "bottleneck"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
@@ -141,7 +144,7 @@ def test_parity_suite_with_fusions_off():
     """The unfused graph (res2 identity blocks as three launches, stem and max-pool as two, stand-alone GroupNorm applies)
     must pass the same backbone / head / episode checks as the default fused one."""
     _rerun({"SYLPH_FUSE_BOTTLENECK": "0", "SYLPH_FUSE_STEM_POOL": "0", "SYLPH_GN_FUSE": "0", "SYLPH_FUSE_GN_LOGITS": "0"},
-           "stem or backbone or head or episode or c3 or full_size_prop")
+           "bf16 and (stem or backbone_fpn or head or episode or c3_full_size or full_size_prop)")
 
 
 _PYRAMID_CHILD = r"""

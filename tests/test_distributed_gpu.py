@@ -185,7 +185,7 @@ def _run_bench(nranks, tmp_path, tag, extra=()):
     args = ["bench.py", "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "128", "--width", "160", "--dtype", "f32",
             "--no-sweep", "--no-parity", "--no-cpu-baseline", "--dump-codes", codes, *extra]
     env = dict(os.environ, SYLPH_BENCH_BACKEND="gloo", SYLPH_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if nranks == 1:
+    if nranks <= 2:  # 2 ranks: plain `python bench.py --gpus 2` -- the script launches its own ranks when WORLD_SIZE is unset
         cmd = [sys.executable] + args
     else:
         with socket.socket() as sk:
