@@ -166,6 +166,10 @@ bool use_hpipe(sylph_ctx* c, const ConvLayer& L, const std::vector<SegDesc>& seg
   const long blocks = (patch_count(segs, 128, 256, 4) + 1) / 2 * (L.Cout / 256), rounds = (blocks + 255) / 256;
   if (hp_on == 2) return true;
   if (blocks >= 512) return blocks * 10 >= rounds * 256 * 8;
+  // Two rounds with a nearly empty second one (backbone conv2 of res4 at 16 images: 280 blocks, 111 us = two block times) lose to
+  // conv_igemm's halo tiles (1120 blocks of 128 x 128, 97 us; profiles/r6_small_batch.md); the pyramid-wide head launches keep the
+  // kernel (their alternative adds the GroupNorm apply passes the fused halo transform saves)
+  if (o.segs_per_image == 1 && blocks > 256 && blocks < 256 + 64) return false;
   // Small batches (round 4): a launch of fewer than 512 blocks is at most two rounds, i.e. it costs one or two block times (~63 us for
   // K = 2304) whatever its fill; the alternative -- conv_igemm on 64-row tiles -- walks the same K as a latency-bound chain (~54 us) and,
   // for a tower layer, adds the GroupNorm finalize + apply launches the fused halo transform makes unnecessary (~40 us at batch 1).

@@ -270,7 +270,12 @@ int build_decode(sylph_ctx* c, Plan* P) {
   RET(c->dalloc((void**)&d.s_level, (size_t)B * pool * 4));
   RET(c->dalloc((void**)&d.s_loc, (size_t)B * pool * 8));
   RET(c->dalloc((void**)&d.s_ord, (size_t)B * pool * 4));
-  RET(c->dalloc((void**)&d.status, 4));
+  RET(c->dalloc((void**)&d.status, 8));
+  // zero once: every decode leaves these zero again (nms_kernel)
+  HIPCHK(hipMemsetAsync(d.cand_count, 0, (size_t)nseg * 4, c->stream));
+  HIPCHK(hipMemsetAsync(d.sel_ws, 0, (size_t)nseg * SEL_WS * 4, c->stream));
+  HIPCHK(hipMemsetAsync(d.pool_count, 0, (size_t)B * 4, c->stream));
+  HIPCHK(hipMemsetAsync(d.status, 0, 8, c->stream));
   RET(c->dalloc((void**)&P->img_out_dev, sizeof(ImageOut) * B));
   HIPCHK(hipHostMalloc((void**)&P->img_out_host, sizeof(ImageOut) * B));
   P->decode_built = true;
@@ -397,7 +402,6 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   const int Npad = (N + bn - 1) / bn * bn;
   RET(ensure_logits(c, P, N, true));
   RET(run_ops(c, P->head_ops, "fcos_head"));
-  KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, c->stream), "pack_codes");
   // the biases, zero-padded to the packed code rows (device copy: the caller's buffer need not outlive this call)
   if (Npad > P->bias_pad_cap) {
     if (P->bias_pad) c->dfree(P->bias_pad);
@@ -406,8 +410,9 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
     P->bias_pad_cap = Npad;
   }
   P->has_bias = c->cfg.cond_use_bias && cls_bias;
-  HIPCHK(hipMemsetAsync(P->bias_pad, 0, (size_t)Npad * sizeof(float), c->stream));
-  if (P->has_bias) HIPCHK(hipMemcpyAsync(P->bias_pad, cls_bias, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  // one launch: packed codes + zero-padded biases + the -inf padded copy the fused scan reads
+  KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, P->has_bias ? cls_bias : nullptr, P->bias_pad, P->bias_pad + P->bias_pad_cap, c->stream),
+       "pack_codes");
   P->scan_fused = false; P->logits_stale = false;
   // Many-way episodes (bf16): conv + scan in one pass, the logits never reach HBM (detect.hip: logits_scan_kernel)
   static const int fuse_scan_on = getenv("SYLPH_FUSE_SCAN") ? atoi(getenv("SYLPH_FUSE_SCAN")) : 1;
@@ -415,9 +420,7 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
     BUILD(build_decode(c, P), P);
     RET(ensure_cand_cap(c, P));
     const DecodeCfg d = decode_cfg(c, P, 0);
-    float* bias_scan = P->bias_pad + P->bias_pad_cap;
-    HIPCHK(hipMemcpyAsync(bias_scan, P->bias_pad, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-    if (Npad > N) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(bias_scan + N), (int)0xff800000u, (size_t)(Npad - N), c->stream));
+    float* bias_scan = P->bias_pad + P->bias_pad_cap;  // written by the pack_codes launch above
     const Plan* PP = P;
     const int nseg = P->B * c->cfg.nlevels;
     KCHK(timed_op(c, "logits_scan_kernel", 2.0 * (double)rows * N * 256.0, c->stream, [=](hipStream_t st) {
@@ -483,28 +486,36 @@ int sylph_decode_nms(sylph_ctx* c, const int* oh, const int* ow, int max_out, fl
   OwnerScope own(c, P);
   BUILD(build_decode(c, P), P);
   RET(ensure_cand_cap(c, P));
-  // img_out_host is rewritten below: wait only for the previous call's H2D copy of it (long finished in steady
-  // state), not for the stream: the host must stay free to launch the next batch on another stream
-  if (P->img_out_ev) HIPCHK(hipEventSynchronize(P->img_out_ev));
-  else HIPCHK(hipEventCreateWithFlags(&P->img_out_ev, hipEventDisableTiming));
+  // postprocess scales of this call; the H2D copy is skipped when they equal what the device table already holds (every step of a
+  // steady query stream).  Otherwise img_out_host is rewritten: wait only for the previous H2D copy of it, not for the stream
+  std::vector<ImageOut> io((size_t)P->B);
   for (int b = 0; b < P->B; ++b) {
     const int H = oh ? oh[b] : P->img_h[b], W = ow ? ow[b] : P->img_w[b];
     // detector_postprocess: python-double ratios cast to the fp32 tensor dtype
-    P->img_out_host[b].sx = (float)((double)W / (double)P->img_w[b]);
-    P->img_out_host[b].sy = (float)((double)H / (double)P->img_h[b]);
-    P->img_out_host[b].out_w = (float)W;
-    P->img_out_host[b].out_h = (float)H;
+    io[b].sx = (float)((double)W / (double)P->img_w[b]);
+    io[b].sy = (float)((double)H / (double)P->img_h[b]);
+    io[b].out_w = (float)W;
+    io[b].out_h = (float)H;
   }
-  HIPCHK(hipMemcpyAsync(P->img_out_dev, P->img_out_host, sizeof(ImageOut) * P->B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipEventRecord(P->img_out_ev, c->stream));
+  if (!P->img_out_ev || P->img_out_last.size() != io.size() || memcmp(P->img_out_last.data(), io.data(), io.size() * sizeof(ImageOut)) != 0) {
+    if (P->img_out_ev) HIPCHK(hipEventSynchronize(P->img_out_ev));
+    else HIPCHK(hipEventCreateWithFlags(&P->img_out_ev, hipEventDisableTiming));
+    memcpy(P->img_out_host, io.data(), io.size() * sizeof(ImageOut));
+    HIPCHK(hipMemcpyAsync(P->img_out_dev, P->img_out_host, sizeof(ImageOut) * P->B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(P->img_out_ev, c->stream));
+    P->img_out_last = io;
+  }
   const DecodeCfg d = decode_cfg(c, P, max_out);
   const int L = c->cfg.nlevels;
+  // the candidate counters are left zero by every decode that ran its own scan; after a fused many-way step (whose launcher clears them
+  // itself and whose candidates stay valid for a repeated decode) the plain scan starts from a cleared table again
+  if (!P->scan_fused && P->cand_dirty) HIPCHK(hipMemsetAsync(P->dbuf.cand_count, 0, (size_t)P->B * L * 4, c->stream));
+  P->cand_dirty = P->scan_fused;
   int nwb = (L * c->cfg.pre_nms_topk + 63) / 64;
   if (nwb > P->pool_cap / 64) nwb = P->pool_cap / 64;
   KCHK(launch_decode(d, P->dsegs, P->B * L, P->hl[0] * P->wl[0], P->B, nwb, P->logits, P->pred, 8, P->dbuf,
-                     P->img_out_dev, boxes, scores, classes, levels, locations, cand, counts, P->scan_fused, c->stream),
+                     P->img_out_dev, boxes, scores, classes, levels, locations, cand, counts, status, P->scan_fused, c->stream),
        "decode_nms");
-  if (status) HIPCHK(hipMemcpyAsync(status, P->dbuf.status, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 

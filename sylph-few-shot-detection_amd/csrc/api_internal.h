@@ -195,6 +195,8 @@ struct Plan {
   bool backbone_built = false, head_built = false, support_built = false;
   ImageDesc* img_desc_dev = nullptr;
   ImageDesc* img_desc_host = nullptr;
+  std::vector<ImageDesc> img_desc_last;  // what img_desc_dev holds (sylph_preprocess skips the H2D copy of an unchanged table)
+  int img_desc_kind = 0;                 // 1: img_desc_dev was written by sylph_preprocess; anything else invalidates the cache
   hipEvent_t img_desc_ev = nullptr;  // recorded after the H2D copy of img_desc_host / rz_host (guards their reuse)
   // fused resize input pipeline: per-image descriptors + PIL coefficient tables (pinned host staging, device copy)
   ResizeDesc* rz_desc_dev = nullptr;
@@ -231,6 +233,7 @@ struct Plan {
   bool stem_takes_raw = false;  // this plan's first backbone op is the fused stem + pool kernel (bf16): it can read raw images
   bool raw_input = false;     // the batch came in through sylph_preprocess and its normalisation is fused into the stem kernel
                               // (launch_stem_pool_raw reads the caller's images through img_desc_dev): x0 has NOT been written
+  bool cand_dirty = false;    // the last decode left the candidate counters non-zero (fused scan: see sylph_decode_nms)
   bool scan_fused = false;    // the candidate buffers were filled by logits_scan_kernel (many-way head): decode skips its scan
   bool logits_stale = false;  // ... and the logits buffer was not written: sylph_export_head runs the unfused conv first
   float* bias_pad = nullptr;  // fp32 class biases of the last sylph_fcos_head: [0, cap) zero-padded to the packed code rows; [cap, 2 cap) the
@@ -239,6 +242,7 @@ struct Plan {
   bool has_bias = false;
   ImageOut* img_out_dev = nullptr;
   ImageOut* img_out_host = nullptr;
+  std::vector<ImageOut> img_out_last;  // what img_out_dev holds (the H2D copy is skipped when a call's scales equal it)
   hipEvent_t img_out_ev = nullptr;  // recorded after the H2D copy of img_out_host (guards its reuse without a stream sync)
   // support
   LevelDesc* lv_dev = nullptr;

@@ -696,7 +696,7 @@ __device__ __forceinline__ bool nms_overlap(float x1, float y1, float x2, float 
 // matrix in HBM: rounds 1-3 built that matrix for ALL chunk pairs in a separate launch (0.19 ms at the headline shape, 0.5 GB).
 __global__ __launch_bounds__(1024) void nms_kernel(const DecodeCfg cfg, const DecodeBuffers buf, const ImageOut* __restrict__ img_out,
                                                    float* out_boxes, float* out_scores, int* out_classes, int* out_levels,
-                                                   float* out_locations, int* out_cand, int* out_counts) {
+                                                   float* out_locations, int* out_cand, int* out_counts, int* status_out, int clear_cands) {
   extern __shared__ unsigned short kept_pos[];  // [pool_cap]: pool positions of the boxes kept so far
   __shared__ unsigned long long s_part[16];
   __shared__ unsigned s_d[64][2];                // suppression bits inside the chunk: word i = boxes of the chunk suppressed by box i
@@ -829,16 +829,34 @@ __global__ __launch_bounds__(1024) void nms_kernel(const DecodeCfg cfg, const De
     if (__any(truncated) && lane == 0) atomicOr(buf.status, 2);
     if (lane == 0) out_counts[img] = nout < cfg.max_out ? nout : cfg.max_out;
   }
+  // Self-cleaning workspace (round 6): this launch is the last reader of the image's counters and selection histograms, so it leaves
+  // them zero for the next decode of the plan -- the four hipMemsetAsync dispatches in front of the scan / the histogram (about 35 us of
+  // a batch-1 step) are gone.  The status word is handed to the caller and cleared by the last block to finish.
+  const int L = cfg.nlevels;
+  __syncthreads();
+  if (t == 0) buf.pool_count[img] = 0u;
+  if (clear_cands && t < L) buf.cand_count[(size_t)img * L + t] = 0u;  // (fused many-way scan: its launcher clears them itself)
+  unsigned* ws = buf.sel_ws + (size_t)img * L * SEL_WS;
+  for (int i = t; i < L * SEL_WS; i += 1024) ws[i] = 0u;
+  if (t == 0) {
+    __threadfence();
+    const int done = atomicAdd(buf.status + 1, 1);
+    if (done == (int)gridDim.x - 1) {
+      __threadfence();
+      const int st = atomicExch(buf.status, 0);
+      if (status_out) *status_out = st;
+      buf.status[1] = 0;
+    }
+  }
 }
 
 int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int max_nloc, int B, int nw_bound,
                   const float* logits, const float* pred, int pred_ld, const DecodeBuffers& buf,
                   const ImageOut* img_out_dev, float* out_boxes, float* out_scores, int* out_classes,
-                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, bool candidates_ready, hipStream_t s) {
-  (void)hipMemsetAsync(buf.pool_count, 0, sizeof(unsigned) * B, s);
-  (void)hipMemsetAsync(buf.status, 0, sizeof(int), s);
+                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, int* status_out, bool candidates_ready, hipStream_t s) {
+  // pool_count, cand_count, sel_ws and the status word are zero on entry: zeroed when the plan's decode buffers are built and left zero
+  // by the previous decode's nms_kernel
   if (!candidates_ready) {  // else logits_scan_kernel has filled the candidate buffers of this batch
-    (void)hipMemsetAsync(buf.cand_count, 0, sizeof(unsigned) * nseg, s);
     // locations per block: at least SCAN_ROWS, and enough for ~16 K scores (a 5-class episode has 8 score slots per location: 64
     // locations would be half a round of the block, and 84 000 such blocks a dispatch-bound launch)
     const int groups = (cfg.num_classes + 3) / 4;
@@ -853,7 +871,6 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
   // 866-way plan (1.8 M slots) 28
   int parts = (cfg.cand_cap + 65535) / 65536;
   parts = parts < 1 ? 1 : (parts > 32 ? 32 : parts);
-  (void)hipMemsetAsync(buf.sel_ws, 0, sizeof(unsigned) * (size_t)nseg * SEL_WS, s);
   hipLaunchKernelGGL(decode_hist_kernel, dim3(parts, nseg), dim3(1024), 0, s, cfg, buf);
   hipLaunchKernelGGL(decode_partition_kernel, dim3(parts, nseg), dim3(1024), 0, s, cfg, segs_dev, buf);
   hipLaunchKernelGGL(decode_finish_kernel, dim3(nseg), dim3(1024), 0, s, cfg, segs_dev, buf);
@@ -861,7 +878,7 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
                      segs_dev, pred, pred_ld, buf);
   (void)nw_bound;
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), sizeof(unsigned short) * cfg.pool_cap, s, cfg, buf, img_out_dev, out_boxes, out_scores,
-                     out_classes, out_levels, out_locations, out_cand, out_counts);
+                     out_classes, out_levels, out_locations, out_cand, out_counts, status_out, candidates_ready ? 0 : 1);
   return (int)hipGetLastError();
 }
 

@@ -530,35 +530,41 @@ int launch_export_nchw_f32(const float* src, float* dst, int C, int HW, int row0
   return (int)hipGetLastError();
 }
 
-// class codes (N,C) fp32 -> packed weight rows [Npad][C] in the compute dtype (zero padded)
-template <typename T>
-__global__ void pack_codes_kernel(const float* __restrict__ w, int N, int C, int Npad, T* __restrict__ out) {
+// class codes (N,C) fp32 -> packed weight rows [Npad][C] in the compute dtype (zero padded); the same launch leaves the class biases
+// zero-padded to Npad in bias_pad (nullptr bias: zeros) and, with bias_scan, a copy with -inf from class N on (logits_scan_kernel:
+// padded classes never pass the threshold) -- one dispatch instead of a kernel, a memset and one or two device copies per head call.
+// SPLIT: every 32-element K-slice as [32 bf16 hi | 32 bf16 lo] (conv_igemm.hip MmaSplit)
+template <typename T, bool SPLIT>
+__global__ void pack_codes_kernel(const float* __restrict__ w, int N, int C, int Npad, T* __restrict__ out, const float* __restrict__ bias,
+                                  float* __restrict__ bias_pad, float* __restrict__ bias_scan) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Npad * C) return;
-  const int n = i / C;
-  out[i] = Cvt<T>::from_f(n < N ? w[i] : 0.f);
-}
-
-// the same for the split-bf16 parity mode: every 32-element K-slice as [32 bf16 hi | 32 bf16 lo] (conv_igemm.hip MmaSplit)
-__global__ void pack_codes_split_kernel(const float* __restrict__ w, int N, int C, int Npad, bf16_t* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Npad) {
+    const float b = (bias && i < N) ? bias[i] : 0.f;
+    if (bias_pad) bias_pad[i] = b;
+    if (bias_scan) bias_scan[i] = i < N ? b : __uint_as_float(0xff800000u);
+  }
   if (i >= Npad * C) return;
   const float v = i / C < N ? w[i] : 0.f;
-  const bf16_t hi = (bf16_t)v;
-  const size_t o = (size_t)(i >> 5) * 64 + (i & 31);  // C % 32 == 0: slices do not straddle rows
-  out[o] = hi;
-  out[o + 32] = (bf16_t)(v - (float)hi);
+  if constexpr (SPLIT) {
+    const bf16_t hi = (bf16_t)v;
+    const size_t o = (size_t)(i >> 5) * 64 + (i & 31);  // C % 32 == 0: slices do not straddle rows
+    out[o] = hi;
+    out[o + 32] = (bf16_t)(v - (float)hi);
+  } else {
+    out[i] = Cvt<T>::from_f(v);
+  }
 }
 
-int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, hipStream_t s) {
+int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, const float* bias, float* bias_pad, float* bias_scan,
+                      hipStream_t s) {
   dim3 grid((Npad * C + 255) / 256), block(256);
   if (dt == DT_F32S) {
     if (C % 32 != 0) return -1;
-    hipLaunchKernelGGL(pack_codes_split_kernel, grid, block, 0, s, w, N, C, Npad, (bf16_t*)out);
+    hipLaunchKernelGGL((pack_codes_kernel<bf16_t, true>), grid, block, 0, s, w, N, C, Npad, (bf16_t*)out, bias, bias_pad, bias_scan);
   } else if (dt == DT_BF16)
-    hipLaunchKernelGGL(pack_codes_kernel<bf16_t>, grid, block, 0, s, w, N, C, Npad, (bf16_t*)out);
+    hipLaunchKernelGGL((pack_codes_kernel<bf16_t, false>), grid, block, 0, s, w, N, C, Npad, (bf16_t*)out, bias, bias_pad, bias_scan);
   else
-    hipLaunchKernelGGL(pack_codes_kernel<float>, grid, block, 0, s, w, N, C, Npad, (float*)out);
+    hipLaunchKernelGGL((pack_codes_kernel<float, false>), grid, block, 0, s, w, N, C, Npad, (float*)out, bias, bias_pad, bias_scan);
   return (int)hipGetLastError();
 }
 

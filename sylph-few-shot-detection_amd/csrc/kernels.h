@@ -64,7 +64,7 @@ struct DecodeBuffers {
   int* s_level;      // [B][pool_cap]
   float* s_loc;      // [B][pool_cap][2]
   unsigned* s_ord;   // [B][pool_cap]
-  int* status;       // [1] bit0: candidate overflow, bit1: output truncated
+  int* status;       // [2] [0] bit0: candidate overflow, bit1: output truncated (handed to the caller and cleared by nms_kernel); [1] nms blocks done
 };
 
 struct ImageOut { float sx, sy, out_w, out_h; };  // postprocess scale + clip box per image
@@ -103,7 +103,7 @@ int launch_relu_rows(DType dt, const void* src, void* dst, int ld, const CopySeg
 int launch_import_nchw(DType dt, const float* src, void* dst, int C, int HW, int row0, int ld, hipStream_t s);
 int launch_export_nchw(DType dt, const void* src, float* dst, int C, int HW, int row0, int ld, hipStream_t s);
 int launch_export_nchw_f32(const float* src, float* dst, int C, int HW, int row0, int ld, int ch0, hipStream_t s);
-int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, hipStream_t s);
+int launch_pack_codes(DType dt, const float* w, int N, int C, int Npad, void* out, const float* bias, float* bias_pad, float* bias_scan, hipStream_t s);
 
 // detect.hip
 // many-way class-conditional conv fused with the scan (detect.hip); x: raw cls-tower output, coef: its GroupNorm (a, b) per
@@ -115,7 +115,7 @@ int launch_logits_scan(const void* x, int ld, const float2* coef, const void* w,
 int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int max_nloc, int B, int nw_bound,
                   const float* logits, const float* pred, int pred_ld, const DecodeBuffers& buf,
                   const ImageOut* img_out_dev, float* out_boxes, float* out_scores, int* out_classes,
-                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, bool candidates_ready, hipStream_t s);
+                  int* out_levels, float* out_locations, int* out_cand, int* out_counts, int* status_out, bool candidates_ready, hipStream_t s);
 
 // codegen.hip
 struct LevelDesc { int row0; int H, W; float scale; };  // per (image, level): rows of the feature pyramid

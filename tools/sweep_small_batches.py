@@ -15,7 +15,7 @@ for b in (1, 2, 4, 8, 16):
     def step():
         eng.preprocess(q); eng.backbone(); eng.head(cw, cb); return eng.decode()
     for _ in range(5): step()
-    torch.cuda.synchronize(); n = 30 if b <= 2 else 10; t = time.perf_counter()
+    torch.cuda.synchronize(); n = 60 if b <= 2 else 30; t = time.perf_counter()
     for _ in range(n): step()
     torch.cuda.synchronize(); out.append(f"B{b} {b * n / (time.perf_counter() - t):.1f}")
 print("  ".join(out))
