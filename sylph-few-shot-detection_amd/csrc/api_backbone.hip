@@ -65,7 +65,7 @@ int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block&
   // first block of res2 (64 -> 64 -> 64 -> 256, projection folded into conv3's GEMM, stride 1): one fused kernel too
   const bool fuse_pr = fuse_bn && dt == DT_BF16 && blk.fused_sc && stride == 1 && mid == 64 && Cin == 64 && cout == 256 &&
                        blk.c1.Cout_pad == 64 && blk.c2.Cout_pad == 64 && blk.c3sc.Cout_pad == 256 && blk.c3sc.Cin == 128 && !blk.c3sc.scale;
-  if ((fuse_id || fuse_pr) && (size_t)B * Hin * Win * 512 < ((size_t)1 << 32)) {  // the kernels address x with 32-bit byte offsets
+  if ((fuse_id || fuse_pr) && (size_t)Hin * Win * 512 < ((size_t)1 << 32) && (size_t)B * Hin * Win < ((size_t)1 << 31)) {  // 32-bit byte offsets inside ONE image (64-bit image base)
     BottleneckArgs ba;
     memset(&ba, 0, sizeof(ba));
     ba.x = X; ba.y = Y;

@@ -209,14 +209,19 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     const int bn = pw_bn, bm = pw_bm;
     const long tiles = ((rows + bm - 1) / bm) * (L.Cout / bn);
     // 32-bit byte offsets into the activation buffers
-    long in_rows = 0, in2_rows = 0, res_rows = 0;
+    // (round 6: the two INPUTS are addressed per segment -- a 64-bit base per image from the tile descriptor + 32-bit offsets inside it --
+    // so only one image has to fit; the residual / output side still offsets the whole tensor: 17 MB per 800 x 1333 image at most)
+    long in_rows = 0, in_rows_all = 0, in2_rows = 0, res_rows = 0, out_rows = 0;
     for (auto& sg : segs) {
-      in_rows = std::max(in_rows, (long)sg.in_row0 + (long)sg.in_H * sg.in_W);
-      in2_rows = std::max(in2_rows, (long)sg.in2_row0 + (long)sg.out_H * o.stride2 * sg.in2_W);
+      in_rows = std::max(in_rows, (long)sg.in_H * sg.in_W);
+      in_rows_all = std::max(in_rows_all, (long)sg.in_row0 + (long)sg.in_H * sg.in_W);  // conv_spw offsets its (narrow) input as a whole
+      in2_rows = std::max(in2_rows, (long)sg.out_H * o.stride2 * sg.in2_W);
       res_rows = std::max(res_rows, (long)sg.res_row0 + (long)sg.res_H * sg.res_W);
+      out_rows = std::max(out_rows, (long)sg.out_row0 + (long)sg.out_H * sg.out_W);
     }
     const bool fits = in_rows * in_ld * 2 < (1L << 32) && (!o.in2 || in2_rows * o.in2_ld * 2 < (1L << 32)) &&
                       (!o.res || res_rows * o.res_ld * 2 < (1L << 32));
+    (void)out_rows;  // (the stores already use 64-bit addresses)
     // Where it pays (in-situ timeline at B = 64, profiles/r3_*): every pointwise layer without a same-geometry residual -- bottleneck
     // conv1 (-13 ... -20 %), conv3 + projection as one GEMM (-14 ... -20 %), FPN laterals incl. the top-down add (-10 ... -15 %) --
     // except the res3-shaped identity conv1 (N = 128, stride 1: already at 5 TB/s in conv_igemm).  With a residual tile to fetch the
@@ -224,7 +229,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     // round 5: a same-geometry residual (conv3 of the identity blocks) takes the streaming variant (conv_spw.hip) on the same operands
     static const int spw_on = getenv("SYLPH_CONV_SPW") ? atoi(getenv("SYLPH_CONV_SPW")) : 1;
     spw = spw_on && o.res_mode == 1 && o.res && L.Cout % 256 == 0 && L.Cout <= 2048 && (L.Cin == 128 || L.Cin == 256 || L.Cin == 512) && o.stride == 1 &&
-          !o.in2 && bm == 128 && bn == 256 && (o.res_ld & 7) == 0 &&
+          !o.in2 && bm == 128 && bn == 256 && (o.res_ld & 7) == 0 && in_rows_all * in_ld * 2 < (1L << 32) &&
           (spw_on == 2 || (rows + bm - 1) / bm >= 512);  // a block owns whole M tiles: at least two per CU
     const bool pays = (o.res_mode != 1 || spw) && (L.Cout % 256 == 0 || o.stride != 1);
     pw = fits && (pw_on == 2 || spw || (tiles >= 256 && pays));
@@ -295,6 +300,16 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     void* pdd = nullptr;
     RET(upload(c, &pdd, pd.data(), pd.size() * sizeof(PwDesc)));
     a.pw_desc = (const PwDesc*)pdd;
+  }
+  if (!hpipe && !pw) {  // conv_igemm indexes its inputs with 31-bit ELEMENT offsets from the tensor base: refuse what would overflow them
+    long in_end = 0, in2_end = 0;
+    for (auto& sg : segs) {
+      in_end = std::max(in_end, ((long)sg.in_row0 + (long)sg.in_H * sg.in_W) * in_ld);
+      if (o.in2) in2_end = std::max(in2_end, ((long)sg.in2_row0 + (long)sg.out_H * o.stride2 * sg.in2_W) * o.in2_ld);
+    }
+    if (in_end >= (1L << 31) || in2_end >= (1L << 31))
+      return fail("batch too large for this layer's kernel: an input of " + std::to_string(std::max(in_end, in2_end)) +
+                  " elements exceeds conv_igemm's 31-bit offsets (split the batch)");
   }
   a.scale = L.scale; a.shift = L.shift; a.zeros = c->zeros;
   a.segs = g.segs; a.tiles = g.tiles; a.n_mtiles = hpipe ? (g.n_mtiles + 1) / 2 : g.n_mtiles; a.n_ntiles = L.Cout_pad / BN;

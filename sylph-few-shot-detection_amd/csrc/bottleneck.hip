@@ -183,8 +183,10 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       while (hx >= HW2) { hx -= HW2; ++hy; }  // (a single step for patches at least 6 wide; narrow maps may wrap twice)
       const int h = r * 8 + xr;
       const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
-      const unsigned off = ((unsigned)(row0 + iy * W + ix) << 9) + (unsigned)((xs ^ (h & 31)) << 4);  // bytes; x < 4 GiB (checked by the host)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(dstb + r * 4096 + wave * 1024), 16, 0, 0);
+      // per-image 64-bit base (wave-uniform, from the tile descriptor) + a 32-bit offset INSIDE the image: no limit on the batch (rounds
+      // 2-5 offset the whole tensor with 32 bits: the fused kernels fell away above 124 images of 800 x 1333)
+      const unsigned off = ((unsigned)(iy * W + ix) << 9) + (unsigned)((xs ^ (h & 31)) << 4);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + ((size_t)(unsigned)row0 << 9) + off), (lds_ptr_t)(dstb + r * 4096 + wave * 1024), 16, 0, 0);
       hx += 8;
     }
   };
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
 #endif
     BK_STAMP(0);
     const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
+    char* const yimg = reinterpret_cast<char*>(y) + (size_t)(unsigned)row0 * (size_t)(C * 2);  // this image's first output row (wave-uniform)
     const int PW = td[5], HW2 = PW + 2, HR = (td[4] + 2) * HW2, NPOS = td[4] * PW;
     const unsigned inv_pw = (unsigned)td[6], inv_hw2 = (unsigned)td[7];
     const int t_next = tile_of(it + 1);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
       const int m = tid;
       const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
       const bool pv = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
-      const unsigned off = pv ? (unsigned)(row0 + (oy0 + my) * IW + ox0 + mx) * (unsigned)(C * 2) : 0xffffffffu;
+      const unsigned off = pv ? (unsigned)((oy0 + my) * IW + ox0 + mx) * (unsigned)(C * 2) : 0xffffffffu;  // inside the image
       *reinterpret_cast<unsigned*>(smem + TAB + ((m >> 5) * 32 + (m & 7) * 4 + ((m >> 3) & 3)) * 4) = off;
     }
     if (DB) {
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64_kernel(const BottleneckAr
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(yo));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          char* dst = yo[q] != 0xffffffffu ? reinterpret_cast<char*>(y) + ((size_t)yo[q] + 128 * wave + (lane & 7) * 16) : trash;
+          char* dst = yo[q] != 0xffffffffu ? yimg + ((size_t)yo[q] + 128 * wave + (lane & 7) * 16) : trash;
 #ifdef BK_NOSTORE
           if (ov[q][0] == 0x12345678u) *reinterpret_cast<u32x4*>(dst) = ov[q];
 #else
@@ -590,8 +593,8 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
       const int h = r * 32 + xr;
       const int hy = (int)(((unsigned)h * inv_hw2) >> 16), hx = h - hy * HW2;
       const int iy = min(max(oy0 - 1 + hy, 0), H - 1), ix = min(max(ox0 - 1 + hx, 0), W - 1);
-      const unsigned off = ((unsigned)(row0 + iy * W + ix) << 7) + (unsigned)((xs ^ ((h >> 1) & 7)) << 4);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + off), (lds_ptr_t)(smem + buf * PX_BYTES + r * 4096 + wave * 1024), 16, 0, 0);
+      const unsigned off = ((unsigned)(iy * W + ix) << 7) + (unsigned)((xs ^ ((h >> 1) & 7)) << 4);  // inside the image; 64-bit image base below
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const char*>(x) + ((size_t)(unsigned)row0 << 7) + off), (lds_ptr_t)(smem + buf * PX_BYTES + r * 4096 + wave * 1024), 16, 0, 0);
     }
   };
   auto relu_pk = [](unsigned u, unsigned keep) {
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
 
   for (int it = 0; t < a.n_tiles; ++it) {
     const int row0 = td[0], IH = td[1], IW = td[2], oy0 = td[3] >> 16, ox0 = td[3] & 0xffff;
+    char* const yimg = reinterpret_cast<char*>(y) + (size_t)(unsigned)row0 * (size_t)(C * 2);  // this image's first output row (wave-uniform)
     const int PW = td[5], HW2 = PW + 2, HR = (td[4] + 2) * HW2, NPOS = td[4] * PW;
     const unsigned inv_pw = (unsigned)td[6], inv_hw2 = (unsigned)td[7];
     const int t_next = tile_of(it + 1);
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
       const int m = tid;
       const int my = (int)(((unsigned)m * inv_pw) >> 16), mx = m - my * PW;
       const bool pv = m < NPOS && oy0 + my < IH && ox0 + mx < IW;
-      const unsigned off = pv ? (unsigned)(row0 + (oy0 + my) * IW + ox0 + mx) * (unsigned)(C * 2) : 0xffffffffu;
+      const unsigned off = pv ? (unsigned)((oy0 + my) * IW + ox0 + mx) * (unsigned)(C * 2) : 0xffffffffu;  // inside the image
       *reinterpret_cast<unsigned*>(smem + PTAB_OFF + ((m >> 5) * 32 + (m & 7) * 4 + ((m >> 3) & 3)) * 4) = off;
     }
 
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void bottleneck64p_kernel(const BottleneckA
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]), "+v"(yo));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          char* dst = yo[q] != 0xffffffffu ? reinterpret_cast<char*>(y) + ((size_t)yo[q] + 128 * wave + (lane & 7) * 16) : trash;
+          char* dst = yo[q] != 0xffffffffu ? yimg + ((size_t)yo[q] + 128 * wave + (lane & 7) * 16) : trash;
           *reinterpret_cast<u32x4*>(dst) = ov[q];
         }
       }

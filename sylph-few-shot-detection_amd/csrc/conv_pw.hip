@@ -132,7 +132,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_pw_kernel(const
   bool ld_valid = valid_at(ld_m);
   if (!ld_valid) return;
   int ld_q = 0, ld_rot = 0, ld_par = 0;
-  unsigned ld_off1[AR], ld_off2[AR];  // byte offsets of this lane's A rows (chunk swizzle included) in `in` / `in2`
+  unsigned ld_off1[AR], ld_off2[AR];  // byte offsets of this lane's A rows (chunk swizzle included) inside the tile's image of `in` / `in2`
+  size_t ld_img1 = 0, ld_img2 = 0;    // ... and the image's first byte (wave-uniform, 64 bits: no limit on the batch for the inputs)
   auto loader_setup = [&]() {
     const int mt = xcd * chunk + ld_m;
     i32x8 d0, d1;
@@ -147,11 +148,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_pw_kernel(const
       const int cl = s4 ^ ((r4 >> 2) & 3);       // source-side swizzle: LDS slot s4 of row r holds logical chunk cl
       int oy = 0, ox = 0;
       if (!direct1 || (in2 && !direct2)) { oy = pos / out_W; ox = pos - oy * out_W; }
-      const int row1 = direct1 ? in_row0 + pos : in_row0 + oy * a.stride * in_W + ox * a.stride;
+      const int row1 = direct1 ? pos : oy * a.stride * in_W + ox * a.stride;
       ld_off1[i] = (unsigned)row1 * (unsigned)(a.in_ld * 2) + cl * 16;
-      const int row2 = direct2 ? in2_row0 + pos : in2_row0 + oy * a.stride2 * in2_W + ox * a.stride2;
+      const int row2 = direct2 ? pos : oy * a.stride2 * in2_W + ox * a.stride2;
       ld_off2[i] = in2 ? (unsigned)row2 * (unsigned)(a.in2_ld * 2) + cl * 16 : 0u;
     }
+    ld_img1 = (size_t)(unsigned)in_row0 * (size_t)(a.in_ld * 2);
+    ld_img2 = (size_t)(unsigned)in2_row0 * (size_t)(a.in2_ld * 2);
   };
   loader_setup();
   const unsigned wvo = (unsigned)tid * 16u;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_pw_kernel(const
     char* dA = smem + stage * STAGE + wave * 1024;  // wave-uniform; lane l lands at +16 l
     char* dB = dA + ASZ;
     const bool second = kp >= nk1;
-    const char* base = second ? in2 + (size_t)(kp - nk1) * 64 : in1 + (size_t)kp * 64;  // wave-uniform
+    const char* base = second ? in2 + ld_img2 + (size_t)(kp - nk1) * 64 : in1 + ld_img1 + (size_t)kp * 64;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const unsigned off = second ? ld_off2[i] : ld_off1[i];

@@ -557,9 +557,12 @@ def test_full_size_properties_bf16(full_sd):
         assert (iou[same] <= 0.75).all()
 
 
-def test_full_size_batch120_far_end_of_the_tensors_bf16(full_sd):
-    """The default bench batch (120 images of 800x1333: activations of up to 4.13e9 bytes, just below the 4-GiB range of the
-    kernels' 32-bit byte offsets, 1.9 x the signed range).  Four distinct images repeated 30 times: every copy of an image must
+@pytest.mark.parametrize("nb", [120, 144])
+def test_full_size_batch120_far_end_of_the_tensors_bf16(full_sd, nb):
+    """The default bench batch (120 images of 800x1333: activations of up to 4.13e9 bytes, just below 4 GiB, 1.9 x the signed 32-bit
+    range) and 144 images (4.95e9 bytes: past the 32-bit range -- since round 6 bottleneck64[p] and conv_pw address their res2-sized
+    operands with a 64-bit base per image + 32-bit offsets inside it; before, those layers fell back to slower kernels above 124
+    images).  Four distinct images repeated nb / 4 times: every copy of an image must
     come out BIT FOR BIT the same wherever it sits in the batch (round 6: conv_hpipe pairs patches per image and keys its K-walk
     rotation on the pair's place inside the image, as conv_pw does since round 5: a served image's detections do not depend on its
     neighbours), and equal its 4-image run (other tile shapes at B = 4) up to bf16 rounding."""
@@ -568,17 +571,17 @@ def test_full_size_batch120_far_end_of_the_tensors_bf16(full_sd):
     codes = W.synthetic_codes(5, seed=4, scale=3.0)
     eng = _engine("bf16", _cfg())
     eng.load_state_dict(full_sd)
-    assert eng.preprocess([base[i % 4] for i in range(120)]) == (800, 1344)
+    assert eng.preprocess([base[i % 4] for i in range(nb)]) == (800, 1344)
     eng.backbone()
     pyr = eng.export_pyramid()
     for lvl, p in enumerate(pyr):
         assert torch.isfinite(p).all()
-        for k in range(1, 30):
+        for k in range(1, nb // 4):
             assert torch.equal(p[0:4], p[4 * k:4 * k + 4]), f"level {lvl}: copy {k} differs from copy 0 by {(p[0:4] - p[4 * k:4 * k + 4]).abs().max().item()}"
     eng.head(codes["cls_conv"], codes["cls_bias"])
     det = eng.decode()
-    assert len(det) == 120
-    for i in range(4, 120):
+    assert len(det) == nb
+    for i in range(4, nb):
         a, b = det[i], det[i % 4]
         assert a["scores"].numel() == b["scores"].numel() > 0
         assert torch.equal(a["cand_index"], b["cand_index"]) and torch.equal(a["scores"], b["scores"]) and torch.equal(a["pred_boxes"], b["pred_boxes"]), \
@@ -591,7 +594,7 @@ def test_full_size_batch120_far_end_of_the_tensors_bf16(full_sd):
     eng4.backbone()
     for lvl, (a, b) in enumerate(zip(small, eng4.export_pyramid())):
         scale = b.abs().max().item()
-        assert (a - b).abs().max().item() <= 4e-2 * scale, f"level {lvl}: batch-120 pyramid vs batch-4 pyramid"
+        assert (a - b).abs().max().item() <= 4e-2 * scale, f"level {lvl}: batch-{nb} pyramid vs batch-4 pyramid"
 
 
 # --------------------------------------------------------------------------------- ROIEncoder (C5)
