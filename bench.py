@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-oracle agreement leg")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not collect roofline.traffic in this run (two rocprofv3 --pmc passes of a short child run of this script); "
-                         "the committed profiles/r5_pmc_hbm_traffic.json is used instead if its source fingerprint matches")
+                         "the committed profiles/r6_pmc_hbm_traffic.json is used instead if its source fingerprint matches")
     ap.add_argument("--dump-codes", default=None, help="rank 0 writes the gathered, normalised class codes (N x 257) to this .pt file (tests)")
     args = ap.parse_args()
 
@@ -563,7 +563,7 @@ def collect_live_pmc(batch):
     """roofline.traffic collected in the run itself: two rocprofv3 passes (--pmc FETCH_SIZE, then --pmc WRITE_SIZE,
     each with --kernel-trace only, as MI355X_MICROARCH.md prescribes: separate passes) of a short child run of this same script at the
     same batch, summarised by tools/rocpd_pmc.py (last query step; FETCH_SIZE doubled on gfx950).  Any failure leaves the committed
-    profiles/r5_pmc_hbm_traffic.json (fingerprint-checked) as the source."""
+    profiles/r6_pmc_hbm_traffic.json (fingerprint-checked) as the source."""
     global _LIVE_PMC
     import shutil
     import subprocess
@@ -602,15 +602,15 @@ def _pmc_file():
         return _LIVE_PMC, "collected in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a 2-step child run)"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from rocpd_pmc_fingerprint import csrc_fingerprint
-    path = os.path.join(ROOT, "profiles", "r5_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r6_pmc_hbm_traffic.json")
     if not os.path.exists(path):
-        return None, "profiles/r5_pmc_hbm_traffic.json is missing"
+        return None, "profiles/r6_pmc_hbm_traffic.json is missing"
     with open(path) as f:
         d = json.load(f)
     if d.get("csrc_fingerprint") != csrc_fingerprint():
-        return None, (f"profiles/r5_pmc_hbm_traffic.json was collected on other kernel sources (fingerprint {d.get('csrc_fingerprint')} != "
+        return None, (f"profiles/r6_pmc_hbm_traffic.json was collected on other kernel sources (fingerprint {d.get('csrc_fingerprint')} != "
                       f"{csrc_fingerprint()}): re-run tools/collect_profiles.sh")
-    return d, "profiles/r5_pmc_hbm_traffic.json"
+    return d, "profiles/r6_pmc_hbm_traffic.json"
 
 
 def pmc_per_kernel_bytes(batch):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun): tools/collect_profiles.sh <tag>
 # kernel-trace summary + separate PMC passes (FETCH_SIZE, WRITE_SIZE) of the default bench command.
-TAG=${1:-r5}; OUT=gpurun_out/$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+TAG=${1:-r6}; OUT=gpurun_out/$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events --no-sweep --no-parity"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1 || echo "trace failed"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o f -- $CMD > $OUT/fetch.log 2>&1 || echo "fetch pass failed"
