@@ -30,10 +30,12 @@ def sd():
     return W.synthetic_state_dict(0, depth=50)
 
 
-@pytest.fixture(scope="module")
-def model(sd):
+@pytest.fixture(scope="module", params=["f32", "f32s"])
+def model(sd, request):
+    """The two modes that carry the north-star's 1e-3 / identical-index statement: exact-fp32 MFMA and split-bf16 (fp32 storage, three
+    bf16 MFMAs per product)."""
     runner, cfg = _cfg()
-    m = runner.build_model(cfg, dtype="f32")
+    m = runner.build_model(cfg, dtype=request.param)
     m.load_state_dict(sd)
     m.eval()
     return m
@@ -83,11 +85,32 @@ def test_runner_episode_matches_oracle(model, sd, ways, shots, nq, bs):
         for g, w in zip(got, want):
             inst = g["instances"]
             assert inst.image_size == (120, 152) and len(inst) == w["scores"].numel() and len(inst) > 0
-            np.testing.assert_array_equal(inst.pred_classes.cpu().numpy(), w["pred_classes"].numpy())
-            np.testing.assert_array_equal(inst.fpn_levels.cpu().numpy(), w["fpn_levels"].numpy())
-            np.testing.assert_array_equal(inst.locations.cpu().numpy(), w["locations"].numpy())
-            np.testing.assert_allclose(inst.scores.cpu().numpy(), w["scores"].numpy(), atol=1e-3)
-            _assert_boxes(inst.pred_boxes.tensor.cpu().numpy(), w["pred_boxes"].numpy(), w["fpn_levels"].numpy())
+            perm = _order(model, inst, w)
+            np.testing.assert_array_equal(inst.pred_classes.cpu().numpy(), w["pred_classes"].numpy()[perm])
+            np.testing.assert_array_equal(inst.fpn_levels.cpu().numpy(), w["fpn_levels"].numpy()[perm])
+            np.testing.assert_array_equal(inst.locations.cpu().numpy(), w["locations"].numpy()[perm])
+            np.testing.assert_allclose(inst.scores.cpu().numpy(), w["scores"].numpy()[perm], atol=1e-3)
+            _assert_boxes(inst.pred_boxes.tensor.cpu().numpy(), w["pred_boxes"].numpy()[perm], w["fpn_levels"].numpy()[perm])
+
+
+def _order(model, inst, w):
+    """Position in the oracle's list of every HIP detection.  Exact-fp32 mode: the identity (the arrays must be equal element by
+    element).  Split-bf16 mode (2^-17 relative per product): the same SET of (level, location, class) triples, and two detections may
+    trade places only where the oracle's own scores are within 1e-4 of each other (the list is sorted by score)."""
+    n = len(inst)
+    if model.engine.dtype != "f32s":
+        return np.arange(n)
+    key = lambda lv, loc, cl: [(int(a), float(b[0]), float(b[1]), int(c)) for a, b, c in zip(lv, loc, cl)]
+    gk = key(inst.fpn_levels.cpu().numpy(), inst.locations.cpu().numpy(), inst.pred_classes.cpu().numpy())
+    wk = key(w["fpn_levels"].numpy(), w["locations"].numpy(), w["pred_classes"].numpy())
+    pos = {k: i for i, k in enumerate(wk)}
+    assert len(pos) == n and set(gk) == set(wk), "different detection sets"
+    perm = np.array([pos[k] for k in gk])
+    moved = np.nonzero(perm != np.arange(n))[0]
+    if moved.size:
+        ws = w["scores"].numpy()
+        assert np.abs(ws[perm[moved]] - ws[moved]).max() <= 1e-4
+    return perm
 
 
 def test_model_contract_errors(model):
