@@ -95,7 +95,6 @@ int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block&
     else ops.push_back([=](hipStream_t s) { return timed_op(c, "bottleneck64p_kernel", fl, s, [=](hipStream_t st) { return launch_bottleneck64p(ba, st); }); });
     return 0;
   }
-  SplitOut fin;
   ConvOpts o1; o1.stride = s1; o1.relu_nch = 1 << 30;
   RET(add_conv(c, ops, blk.c1, X, Cin, t1, mid, image_segs(B, Hin, Win, H1, W1), o1));
   // res3 conv2 (3x3, 128 -> 128, stride 1), bf16: weights in registers, LDS holds only the activation halo (conv_rw3.hip)
@@ -124,25 +123,7 @@ int add_bottleneck(sylph_ctx* c, std::vector<OpFn>& ops, const sylph_ctx::Block&
     ops.push_back([=](hipStream_t s) { return timed_op(c, "conv_rw3_kernel", fl, s, [=](hipStream_t st) { return launch_conv_rw3(ba, st); }); });
   } else {
     ConvOpts o2; o2.stride = s3; o2.pad = 1; o2.relu_nch = 1 << 30;
-    // identity blocks at small batches: when conv2 runs split along K, its finish pass and conv3 are ONE launch (conv_igemm.hip
-    // finish_pw_kernel): two dependent ~10-us launches become one
-    static const int finpw_on = getenv("SYLPH_FINISH_PW") ? atoi(getenv("SYLPH_FINISH_PW")) : 1;
-    if (finpw_on && dt == DT_BF16 && !blk.fused_sc && !blk.has_sc && s3 == 1 && (mid == 256 || mid == 512) && blk.c3.Cin == mid && blk.c3.KH == 1 &&
-        blk.c3.Cout == cout && blk.c3.Cout_pad == cout && cout % 128 == 0 && blk.c2.Cout_pad == mid && blk.c2.scale && blk.c2.shift)
-      o2.split_out = &fin;
     RET(add_conv(c, ops, blk.c2, t1, mid, t2, mid, image_segs(B, H1, W1, Ho, Wo), o2));
-  }
-  if (fin.ks > 0) {
-    const SplitOut f = fin;
-    const float *s2p = blk.c2.scale, *b2p = blk.c2.shift, *s3p = blk.c3.scale, *b3p = blk.c3.shift;
-    const void* w3 = blk.c3.w;
-    const double fl = 2.0 * (double)B * Ho * Wo * (double)mid * cout;
-    ops.push_back([=](hipStream_t s) {
-      return timed_op(c, "finish_pw_kernel", fl, s, [=](hipStream_t st) {
-        return launch_finish_pw(f.slot ? *f.slot : f.own, f.ks, f.plane, f.rows, mid, s2p, b2p, 1, w3, cout, s3p, b3p, X, cout, 1, Y, cout, st);
-      });
-    });
-    return 0;
   }
   if (blk.fused_sc) {
     // conv3 + projection shortcut as ONE pointwise GEMM over K = [t2 | X(strided)]: the shortcut

@@ -403,19 +403,6 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
       const float *scl = L.scale, *shf = L.shift;
       const void* resp = o.res_mode == 1 ? o.res : nullptr;
       const int res_ld = o.res_ld, relu_nch = o.relu_nch, Cout = L.Cout, nseg = (int)ss.size();
-      bool compact = o.res_mode == 0;  // the planes' row numbering is the output's own (images stored back to back)
-      for (auto& q : ss) compact = compact && q.src_row0 == q.dst_row0;
-      if (o.split_out && compact) {  // the caller finishes the planes inside the consumer's launch
-        o.split_out->ks = ks; o.split_out->slot = slot; o.split_out->own = own; o.split_out->plane = plane; o.split_out->rows = r0;
-        ops.push_back([=](hipStream_t s) {
-          return timed_op(c, "conv_igemm_kernel", flops, s, [=](hipStream_t st) {
-            ConvArgs bb = b;
-            bb.out = slot ? *slot : own;
-            return launch_conv(dt, true, bb, BM, BN, st);
-          });
-        });
-        return 0;
-      }
       ops.push_back([=](hipStream_t s) {
         return timed_op(c, "conv_igemm_kernel", flops, s, [=](hipStream_t st) {
           float* partial = slot ? *slot : own;

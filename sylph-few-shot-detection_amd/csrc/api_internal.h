@@ -269,16 +269,6 @@ struct Geom {
   float* gn_partial = nullptr;  // per-tile GroupNorm partials written by the conv epilogue (want_gn)
 };
 
-// add_conv hands a split-K launch's partial planes to the caller instead of finishing them (the caller fuses the finish into the
-// consumer: api_backbone.hip, conv2 -> conv3 of an identity bottleneck)
-struct SplitOut {
-  int ks = 0;                 // 0: the layer was not split (add_conv built the usual launch)
-  float** slot = nullptr;     // the plan's scratch slot holding the planes (read at launch time) ...
-  float* own = nullptr;       // ... or a buffer of the op's own (no owning plan)
-  size_t plane = 0;           // elements per plane
-  int rows = 0;               // rows of a plane (compact numbering)
-};
-
 struct ConvOpts {
   int stride = 1, pad = 0;
   int relu_nch = 0, mul_nch = 0;
@@ -295,7 +285,6 @@ struct ConvOpts {
   const float2* gn_coef = nullptr;  // fused GroupNorm(+ReLU) of the INPUT (conv_hpipe.hip): (a, b) per (segment, input channel)
   int gn_relu = 0;
   int segs_per_image = 1;  // consecutive segments that belong to one image (pyramid-wide launches: the FPN levels)
-  SplitOut* split_out = nullptr;  // see SplitOut: only honoured when the segments' compact row numbering equals the output's rows and there is no residual
   int stream_slot = 0;     // 1: the op will run on the context's side stream (its split-K scratch must not be the main stream's)
 };
 

@@ -177,9 +177,6 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a, int BM, int BN, hipSt
 void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN);
 int launch_splitk_finish(const float* partial, int ksplit, size_t plane, int ld, int Cout, const SplitSeg* segs_dev, int nseg, int max_rows,
                          const float* scale, const float* shift, const void* res, int res_ld, int relu_nch, void* out, int out_ld, hipStream_t s);
-// split-K finish fused with the following pointwise conv (identity bottleneck conv2 -> conv3 at small batches; conv_igemm.hip)
-int launch_finish_pw(const float* partial, int ks, size_t plane, int rows, int K, const float* s2, const float* b2, int relu2, const void* w3,
-                     int Cout, const float* s3, const float* b3, const void* res, int res_ld, int relu3, void* out, int out_ld, hipStream_t s);
 // conv_hpipe.hip: 256x256 deep-pipelined halo-operand 3x3 kernel (BM == BN == 256 selects it in launch_conv; the tile
 // table then holds PAIRS of patches and n_mtiles counts the pairs)
 bool conv_hpipe_ok(DType dt, bool out_f32, const ConvArgs& a);

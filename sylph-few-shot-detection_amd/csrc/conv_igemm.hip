@@ -711,147 +711,6 @@ int launch_splitk_finish(const float* partial, int ksplit, size_t plane, int ld,
   return (int)hipGetLastError();
 }
 
-// ---- split-K finish + the following pointwise conv in ONE launch (small batches, round 6) ---------------------------------------------
-// The conv2 -> conv3 pair of an identity bottleneck at batch 1-4: conv2 runs split along K and leaves ks fp32 partial planes; instead of
-// splitk_finish_kernel (planes -> bf16 t2) followed by conv_igemm (t2 -> y) -- two dependent launches of ~10 us each on a mostly idle
-// chip -- a block takes 32 rows: it reduces their planes in plane order, applies conv2's FrozenBN + ReLU and rounds to bf16 (the
-// rounding point of the finish kernel) into an LDS A tile [32][K], keeps the tile's MFMA fragments in registers, and walks its share of
-// conv3's output channels in 32-channel chunks with the weight fragments loaded straight from L2 (double-buffered, no LDS), epilogue
-// scale / shift + residual + ReLU in the accumulator layout.  Same rounding points and the same K order as the two-launch path: the
-// results are bit-identical (tests/test_conv_variants_gpu.py).  grid = (row tiles, N shares).
-struct FinPwArgs {
-  const float* partial; int ks; size_t plane; int rows;   // [ks][rows][K] fp32, compact row numbering = the activation's rows
-  const float *s2, *b2; int relu2;                         // conv2's epilogue
-  const bf16_t* w3; int Cout; const float *s3, *b3;        // conv3: [Cout][K] bf16, epilogue tables
-  const bf16_t* res; int res_ld; int relu3;                // same-geometry residual (may be null)
-  bf16_t* out; int out_ld;
-};
-
-template <int K>
-__global__ __launch_bounds__(256, 1) void finish_pw_kernel(const FinPwArgs a) {
-  constexpr int CPR = K / 8;    // 16-byte chunks per A row
-  constexpr int KS = K / 16;    // MFMA k-steps
-  constexpr int MAXKS = 8;      // add_conv splits K at most 8 ways
-  __shared__ __attribute__((aligned(16))) char sA[32 * K * 2];
-  __shared__ __attribute__((aligned(16))) float sS3[2048], sB3[2048];  // conv3's scale / shift of this block's channels
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * 32;
-  const int per = a.Cout / (int)gridDim.y, nb = blockIdx.y * per, nchunks = per >> 5;
-  for (int i = tid; i < per; i += 256) { sS3[i] = a.s3 ? a.s3[nb + i] : 1.f; sB3[i] = a.b3 ? a.b3[nb + i] : 0.f; }
-  // A tile: finish of conv2 for rows m0 .. m0 + 31 (rows past the end: zeros).  Every load of a chunk is issued before the first add
-  // (a plane-by-plane loop would be ks dependent HBM / L2 round trips on a nearly empty chip); the adds keep the plane order.
-#pragma unroll
-  for (int q = 0; q < 32 * CPR / 256; ++q) {
-    const int idx = tid + 256 * q;
-    const int row = idx / CPR, ch = idx - row * CPR;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-#ifdef FPW_NOA
-    if (false) {
-#else
-    if (m0 + row < a.rows) {
-#endif
-      const float* src = a.partial + (size_t)(m0 + row) * K + ch * 8;
-      float4 lo[MAXKS], hi[MAXKS];
-#pragma unroll
-      for (int k = 0; k < MAXKS; ++k)
-        if (k < a.ks) { lo[k] = *reinterpret_cast<const float4*>(src + k * a.plane); hi[k] = *reinterpret_cast<const float4*>(src + k * a.plane + 4); }
-      const float4 sl = a.s2 ? *reinterpret_cast<const float4*>(a.s2 + ch * 8) : make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 sh = a.s2 ? *reinterpret_cast<const float4*>(a.s2 + ch * 8 + 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 bl = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + ch * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 bh = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + ch * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < MAXKS; ++k)
-        if (k < a.ks) {
-          v[0] += lo[k].x; v[1] += lo[k].y; v[2] += lo[k].z; v[3] += lo[k].w; v[4] += hi[k].x; v[5] += hi[k].y; v[6] += hi[k].z; v[7] += hi[k].w;
-        }
-      const float sc[8] = {sl.x, sl.y, sl.z, sl.w, sh.x, sh.y, sh.z, sh.w}, bs[8] = {bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bs[e];
-      if (a.relu2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      }
-    }
-    store8<bf16_t>(reinterpret_cast<bf16_t*>(sA + (row * CPR + (ch ^ (row & 15))) * 16), v);
-  }
-  __syncthreads();
-  bf16x8 af[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(sA + (l31 * CPR + ((ks * 2 + lh) ^ (l31 & 15))) * 16);
-  // this block's share of the output channels, in 32-channel chunks dealt to the four waves
-  const bool rowv = m0 + l31 < a.rows;
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-  auto load_w = [&](int c, bf16x8 (&wf)[KS], bf16x4 (&rs)[4]) {  // weight fragments + the residual values of chunk c
-    const bf16_t* wp = a.w3 + (size_t)(nb + c * 32 + l31) * K + lh * 8;
-#ifdef FPW_NOW
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = af[ks];
-    (void)wp;
-#else
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(wp + ks * 16);
-#endif
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      rs[g] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-      if (a.res && rowv) rs[g] = *reinterpret_cast<const bf16x4*>(a.res + (size_t)(m0 + l31) * a.res_ld + nb + c * 32 + 4 * lh + 8 * g);
-    }
-  };
-  auto chunk = [&](int c, const bf16x8 (&wf)[KS], const bf16x4 (&rs)[4]) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], af[ks], acc, 0, 0, 0);  // D^T: 4 consecutive channels per lane
-    if (!rowv) return;
-    const int nl = c * 32 + 4 * lh;  // inside the block's share
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 sv = *reinterpret_cast<const float4*>(sS3 + nl + 8 * g), bv = *reinterpret_cast<const float4*>(sB3 + nl + 8 * g);
-      float v[4] = {acc[4 * g] * sv.x + bv.x, acc[4 * g + 1] * sv.y + bv.y, acc[4 * g + 2] * sv.z + bv.z, acc[4 * g + 3] * sv.w + bv.w};
-      if (a.res) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rs[g][e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)((a.relu3 && v[e] < 0.f) ? 0.f : v[e]);
-#ifdef FPW_NOST
-      if (v[0] == 1234.5f)
-#endif
-      *reinterpret_cast<bf16x4*>(a.out + (size_t)(m0 + l31) * a.out_ld + nb + nl + 8 * g) = o;
-    }
-  };
-  bf16x8 w0[KS], w1[KS];
-  bf16x4 r0[4], r1[4];
-  int c = wave;
-  if (c < nchunks) load_w(c, w0, r0);
-  for (; c < nchunks; c += 8) {
-    if (c + 4 < nchunks) load_w(c + 4, w1, r1);
-    chunk(c, w0, r0);
-    if (c + 4 < nchunks) {
-      if (c + 8 < nchunks) load_w(c + 8, w0, r0);
-      chunk(c + 4, w1, r1);
-    }
-  }
-}
-
-int launch_finish_pw(const float* partial, int ks, size_t plane, int rows, int K, const float* s2, const float* b2, int relu2, const void* w3,
-                     int Cout, const float* s3, const float* b3, const void* res, int res_ld, int relu3, void* out, int out_ld, hipStream_t s) {
-  if ((K != 256 && K != 512) || Cout % 128 != 0 || Cout > 2048 || (out_ld & 3) || (res && (res_ld & 3)) || rows <= 0 || ks < 1 || ks > 8) return -1;
-  FinPwArgs a{partial, ks, plane, rows, s2, b2, relu2, (const bf16_t*)w3, Cout, s3, b3, (const bf16_t*)res, res_ld, relu3, (bf16_t*)out, out_ld};
-  const int mt = (rows + 31) / 32;
-  int nsplit = (256 + mt - 1) / mt;  // about one block per CU
-  if (nsplit > Cout / 128) nsplit = Cout / 128;
-  while (nsplit > 1 && (Cout / 32) % nsplit != 0) --nsplit;
-  if (nsplit < 1) nsplit = 1;
-  if (K == 256) hipLaunchKernelGGL(finish_pw_kernel<256>, dim3(mt, nsplit), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(finish_pw_kernel<512>, dim3(mt, nsplit), dim3(256), 0, s, a);
-  return (int)hipGetLastError();
-}
-
 #ifdef SYLPH_ABLATE
 static int g_nbuf = 1;  // A/B knob: a second LDS stage (rejected)
 void conv_set_nbuf(int n) { g_nbuf = n == 2 ? 2 : 1; }
