@@ -463,7 +463,7 @@ def baseline_config_legs(args, device, local_rank):
     """Untimed extras (same JSON line): the OTHER BASELINE.json configurations on one GPU, each with its own work count --
       c2_r50_20way_10shot : configs[2]  R-50-FPN, COCO 20 novel classes, 10-shot, batch 16 queries of 800x1333
       c4_r101_866way      : configs[3]  R-101-FPN, LVIS freq + common = 866 classes, 5-shot (4 330 support images per episode),
-                                         64 queries of 800x1333 per step (one rank's share of the 8-GPU job; the code all-gather is not in it)
+                                         120 queries of 800x1333 per step (one rank's share of the 8-GPU job; the code all-gather is not in it; rounds 4-5: 64 per step)
       c5_roi_encoder_337way: configs[4] ROI-Encoder code generator + CondConvBlock head, LVIS rare = 337 classes, 5-shot, 800x1200 queries
     Per leg: img_s (query steps, two in flight, codes resident), support_img_s (steady-state support batches of 12 classes through
     backbone -> code generator), gflop_per_image = the library's own 2 M N K count over the conv launches of a query step,
@@ -543,14 +543,14 @@ def baseline_config_legs(args, device, local_rank):
     legs["c2_r50_20way_10shot"]["config"] = "BASELINE configs[2]: R-50-FPN COCO 20 novel classes, 10-shot, batch 16 queries"
     cfg4 = make_cfg()
     cfg4.MODEL.RESNETS.DEPTH = 101
-    legs["c4_r101_866way"] = run_leg(cfg4, W.synthetic_state_dict(0, depth=101), 64, args.height, args.width, 866, 5, 300)
+    legs["c4_r101_866way"] = run_leg(cfg4, W.synthetic_state_dict(0, depth=101), 120, args.height, args.width, 866, 5, 300)
     legs["c4_r101_866way"]["config"] = ("BASELINE configs[3]: R-101-FPN LVISv1 Meta-FCOS, 866-way 5-shot; one rank's query share of the 8-GPU job "
                                         "(the code all-gather over xGMI is not part of a query step)")
     runner = MetaFCOSROIEncoderRunner()
     cfg5 = create_cfg(runner.get_default_cfg(), "sylph://LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml", ["MODEL.META_LEARN.EVAL_SHOT", 5])
     sd5 = {}
     sd5.update(W.backbone_state_dict(0, depth=50)); sd5.update(W.head_state_dict(1, num_classes=60)); sd5.update(W.roi_encoder_state_dict(seed=4))
-    legs["c5_roi_encoder_337way"] = run_leg(cfg5, sd5, 64, 800, 1200, 337, 5, 300)
+    legs["c5_roi_encoder_337way"] = run_leg(cfg5, sd5, 120, 800, 1200, 337, 5, 300)
     legs["c5_roi_encoder_337way"]["config"] = ("BASELINE configs[4]: ROI-Encoder code generator + CondConvBlock head (Meta-FCOS-ROI-Encoder-finetune.yaml), "
                                                "LVIS rare 337-way 5-shot, 800x1200 queries; one rank's share of the 4-GPU job")
     return legs
