@@ -31,4 +31,6 @@ def run(nstreams, B, iters=8):
     print(f"streams={nstreams} B/stream={B}: {nstreams * B * iters / dt:8.1f} img/s (no decode)", flush=True)
     del engs
 
-run(1, 64); run(2, 32); run(2, 64); run(3, 64); run(1, 64)
+import sys as _s
+for spec in (_s.argv[1:] or ["1x64", "2x32", "2x64", "3x64", "1x64"]):
+    n, b = spec.split("x"); run(int(n), int(b))
