@@ -71,11 +71,13 @@ def _cand_ordinals(inst, Hp, Wp, N):
     return (np.asarray(bases)[inst["fpn_levels"].numpy()] + inst["loc_index"].numpy()) * N + inst["pred_classes"].numpy()
 
 
-def test_c5_episode_f32_matches_oracle(sd):
+@pytest.mark.parametrize("mode", ["f32", "f32s"])
+def test_c5_episode_f32_matches_oracle(sd, mode):
+    """`mode`: the exact-fp32 MFMA mode and the split-bf16 parity mode (fp32 storage, three bf16 MFMAs per conv product)."""
     from oracle import backbone as OB, decode as OD, head as OH
     from sylph_amd.data import SyntheticQueryLoader, SyntheticSupportSetLoader
     runner, cfg = _runner_cfg()
-    model = runner.build_model(cfg, dtype="f32")
+    model = runner.build_model(cfg, dtype=mode)
     model.load_state_dict(sd)
     model.eval()
     assert model.engine.is_roi_encoder and abs(model.engine.cond_scale - 0.8) < 1e-6

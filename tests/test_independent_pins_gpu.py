@@ -49,7 +49,7 @@ def test_hip_roi_align_matches_separable_float64():
     assert levels == {3, 4, 5, 6, 7}
 
 
-@pytest.mark.parametrize("dtype,rel", [("f32", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,rel", [("f32", 1e-3), ("f32s", 1e-3), ("bf16", 3e-2)])
 def test_hip_fpn_matches_hf_neck_on_its_own_stage_outputs(dtype, rel):
     """FPN laterals + fused nearest-2x top-down adds + 3x3 output convs + P6 / P7 of the HIP backbone, from the HIP path's OWN res3..res5
     (parity taps), against Sam2VisionNeck + float64 sums: pins the FPN half independently of the ResNet half (that one is pinned

@@ -155,7 +155,7 @@ def test_fpn_step_known_answer_f32(g8):
     _close(p4[0].cpu().numpy(), g8["fpn_p4"], 1e-4)
 
 
-@pytest.mark.parametrize("dtype,rel", [("f32", 1e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,rel", [("f32", 1e-3), ("f32s", 1e-3), ("bf16", 6e-2)])
 def test_resnet50_fpn_known_answer(g8, dtype, rel):
     """The whole backbone + FPN + P6/P7 (fused top-down upsample, fused projection shortcuts, stem kernel, maxpool) on a
     64 x 96 image vs the float64 result: fp32 mode within the north-star 1e-3; bf16 mode: the bound is the measured
