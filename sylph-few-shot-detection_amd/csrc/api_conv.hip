@@ -66,7 +66,7 @@ void set_patch(SegDesc* s, int ph, int pw, int xpad) {
 // patches per block): the patch list of every IMAGE (`group` consecutive segments) is padded to an even length with an empty patch, so a
 // pair never straddles two images, and the first tile of a pair carries the pair's index INSIDE its image in tile.x >> 20 (the kernel's
 // K-walk rotation key; tile.x & 0xfffff = segment): an image's results do not depend on where in the batch it sits.  Images that would
-// grow by more than 1/8 (one-patch ROI maps) keep the flat pairing.
+// grow by more than 1/8 (one-patch ROI maps) keep the flat pairing and the global pair index as the key.
 int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int halo_rows, int xpad, bool pair, Geom* g, int group) {
   std::vector<int2> tiles;
   static const int fixed = SYLPH_AB_ENV("SYLPH_CONV_PATCH_8X16", 0);  // A/B knob (-DSYLPH_ABLATE builds): the round-1 geometry
@@ -93,6 +93,8 @@ int make_geom_patch(sylph_ctx* c, std::vector<SegDesc> segs, int max_pos, int ha
     }
   }
   if (pair && (tiles.size() & 1)) tiles.push_back(make_int2(0, 0x7fff << 16));
+  if (pair && !per_image)  // flat pairing (tiny maps): the rotation key is the global pair index, as in rounds 2-5
+    for (size_t t = 0; t < tiles.size(); t += 2) tiles[t].x |= (int)(((t >> 1) & 0x7ff) << 20);
   g->n_mtiles = (int)tiles.size();
   void *ds = nullptr, *dtl = nullptr;
   RET(upload(c, &ds, segs.data(), segs.size() * sizeof(SegDesc)));
