@@ -24,6 +24,12 @@
 //   * barriers per tile (all eight waves): one per phase, one when the K loop is done and the residual has landed (the S waves wait
 //     vmcnt(0) first), one when the epilogue is done.
 //
+// Round 6: the same structure for three more pointwise layers whose weights fit the registers (K <= 512 per 256-channel N tile) and that
+// ran on conv_pw at 3.2-4.1 TB/s: RESM = 0 (no residual: the buffer is store staging only) with a STRIDED input (stride-2 conv1 of the
+// first res4 block) and / or a SECOND K range from a second, strided input (conv3 + projection shortcut of the first res3 block as one
+// GEMM, K = 128 + 256); RESM = 2 (the residual is the nearest-2x upsampled coarser map: FPN lateral3 + top-down add).  Inputs are
+// addressed with a 64-bit base per image + 32-bit offsets inside it.
+//
 // Numerics: the rounding points of conv_pw / conv_igemm (fp32 accumulate, fma(acc, scale, shift) + residual, ReLU, bf16).
 #include <stdlib.h>
 
@@ -76,12 +82,13 @@ constexpr int SPW_LDS = BUF_OFF + BUF;  // 133 120
 static_assert(SPW_LDS <= 160 * 1024, "LDS budget");
 }  // namespace
 
-// K = input channels (128 / 256 / 512): the weight fragments a wave holds are indexed by compile-time k-steps
-template <int K, bool RELU>
+// K = input channels (128 / 256 / 384 / 512; a.Cin of them from `in`, the rest from `in2`): the weight fragments a wave holds are indexed
+// by compile-time k-steps.  RESM: 0 no residual, 1 same-geometry residual, 2 nearest-2x upsampled residual.
+template <int K, int RESM, bool RELU>
 __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
   constexpr int NK = K / 64;                  // 64-channel phases per tile
   constexpr int KS = K / 16;                  // MFMA k-steps = weight fragments per wave (4 VGPRs each)
-  constexpr int UNR_OUT = K == 512 ? 1 : 4, UNR_IN = K == 512 ? 2 : 16;  // streamer loops: K = 512 leaves no registers to unroll them
+  constexpr int UNR_OUT = K >= 384 ? 1 : 4, UNR_IN = K >= 384 ? 2 : 16;  // streamer loops: K = 512 leaves no registers to unroll them
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -123,28 +130,40 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
   // runs NST - 1 phases ahead of the MFMAs, across tile boundaries --------------------------------------------------------------------
   const int r8 = lane >> 3, s8 = lane & 7;
   const char* const in1 = reinterpret_cast<const char*>(a.in);
+  const char* const in2 = reinterpret_cast<const char*>(a.in2);
+  const int nk1 = a.in2 ? (a.Cin >> 6) : NK;  // phases read from `in`; the rest from `in2`
   int ld_m = cur_m, ld_q = 0;
   bool ld_valid = true;
-  unsigned ld_off[4];
+  unsigned ld_off[4], ld_off2[4];     // byte offsets of this lane's rows inside the tile's image of `in` / `in2` (swizzle included)
+  size_t ld_img1 = 0, ld_img2 = 0;    // the image's first byte (wave-uniform)
   auto loader_setup = [&]() {
     i32x8 d0, d1;
     load_desc(xcd * chunk + ld_m, d0, d1);
-    const int row0 = d0[0], seg_rows = d0[1], in_row0 = d0[4];
+    const int row0 = d0[0], seg_rows = d0[1], out_W = d0[2], in_row0 = d0[4], in_W = d0[5], in2_row0 = d0[6], in2_W = d0[7];
+    const bool direct1 = a.stride == 1 && in_W == out_W, direct2 = a.stride2 == 1 && in2_W == out_W;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rc = wave * 32 + 8 * k + r8;
       int pos = row0 + rc;
       pos = pos < seg_rows ? pos : seg_rows - 1;
-      ld_off[k] = (unsigned)(in_row0 + pos) * (unsigned)(a.in_ld * 2) + (unsigned)((s8 ^ (rc & 7)) << 4);
+      int oy = 0, ox = 0;
+      if (!direct1 || (in2 && !direct2)) { oy = pos / out_W; ox = pos - oy * out_W; }
+      const int row1 = direct1 ? pos : oy * a.stride * in_W + ox * a.stride;
+      ld_off[k] = (unsigned)row1 * (unsigned)(a.in_ld * 2) + (unsigned)((s8 ^ (rc & 7)) << 4);
+      const int row2 = direct2 ? pos : oy * a.stride2 * in2_W + ox * a.stride2;
+      ld_off2[k] = in2 ? (unsigned)row2 * (unsigned)(a.in2_ld * 2) + (unsigned)((s8 ^ (rc & 7)) << 4) : 0u;
     }
+    ld_img1 = (size_t)(unsigned)in_row0 * (size_t)(a.in_ld * 2);
+    ld_img2 = (size_t)(unsigned)in2_row0 * (size_t)(a.in2_ld * 2);
   };
   if (loader) loader_setup();
   auto issue_one = [&](int stage) -> int {
     if (!ld_valid) return 0;
     char* d = smem + stage * STAGE + wave * 4096;
-    const char* base = in1 + (size_t)ld_q * 128;
+    const bool second = ld_q >= nk1;
+    const char* base = second ? in2 + ld_img2 + (size_t)(ld_q - nk1) * 128 : in1 + ld_img1 + (size_t)ld_q * 128;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + ld_off[k]), (lds_ptr_t)(d + k * 1024), 16, 0, 0);
+    for (int k = 0; k < 4; ++k) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + (second ? ld_off2[k] : ld_off[k])), (lds_ptr_t)(d + k * 1024), 16, 0, 0);
     if (++ld_q == NK) {
       ld_q = 0;
       ld_m += m_step;
@@ -184,13 +203,17 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
       }
     }
   };
-  auto res_in = [&](int row0, int seg_rows, int res_row0) {  // this tile's residual rows into the buffer (whole lines, source-side swizzle)
+  auto res_in = [&](int row0, int seg_rows, int res_row0, int out_W, int res_W) {  // this tile's residual rows into the buffer (whole lines, source-side swizzle)
     char* const region_p = smem + BUF_OFF + sg * 16384;
 #pragma unroll UNR_IN
     for (int k = 0; k < 16; ++k) {
       const int rc = 8 * k + r8;
       int pos = row0 + rc;
       pos = pos < seg_rows ? pos : seg_rows - 1;
+      if (RESM == 2) {  // nearest-2x upsample of the coarser map (FPN top-down path)
+        const int oy = pos / out_W, ox = pos - oy * out_W;
+        pos = (oy >> 1) * res_W + (ox >> 1);
+      }
       const char* src = resb + ((size_t)(res_row0 + pos) * a.res_ld + scol + ((s8 ^ (rc & 7)) << 3)) * 2;
 #ifdef SPW_NORES
       if (src == nullptr) *reinterpret_cast<volatile int*>(region_p) = 0;
@@ -210,11 +233,11 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
   int ring = 0;
 
   while (true) {
-    int row0 = 0, seg_rows = 0, out_row0 = 0, res_row0 = 0;
+    int row0 = 0, seg_rows = 0, out_row0 = 0, res_row0 = 0, out_W = 1, res_W = 1;
     if (streamer) {
       i32x8 d0, d1;
       load_desc(xcd * chunk + cur_m, d0, d1);
-      row0 = d0[0]; seg_rows = d0[1]; out_row0 = d0[3]; res_row0 = d1[0];
+      row0 = d0[0]; seg_rows = d0[1]; out_W = d0[2]; out_row0 = d0[3]; res_row0 = d1[0]; res_W = d1[1];
     }
     f32x16 acc[4];
 #pragma unroll
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
         // phase 0: every wave is past barrier B of the previous tile, the buffer holds its result: out with it, then this tile's
         // residual in (both under this tile's K loop)
         if (have_prev) out_prev();
-        res_in(row0, seg_rows, res_row0);
+        if (RESM != 0) res_in(row0, seg_rows, res_row0, out_W, res_W);
       }
       const unsigned tS = lds0 + ring * STAGE;
 #pragma unroll
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
     }
     if (streamer) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's residual has landed (and the previous tile is out)
     SP_BAR();  // A: K loop done everywhere, residual in the buffer
-    if constexpr (K <= 256) {
+    if constexpr (K <= 384) {
       f32x4v sc4[4], sh4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -270,9 +293,11 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned rg = region + i * 4096;
-        u32x2 rv[4];
+        u32x2 rv[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+        if (RESM != 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("ds_read_b64 %0, %1" : "=v"(rv[g]) : "v"(rg + (((4 * hb + g) ^ (l31 & 7)) << 4)));
+          for (int g = 0; g < 4; ++g) asm volatile("ds_read_b64 %0, %1" : "=v"(rv[g]) : "v"(rg + (((4 * hb + g) ^ (l31 & 7)) << 4)));
+        }
         if (i == 0)
           asm volatile("s_waitcnt lgkmcnt(0)"
                        : "+v"(sc4[0]), "+v"(sc4[1]), "+v"(sc4[2]), "+v"(sc4[3]), "+v"(sh4[0]), "+v"(sh4[1]), "+v"(sh4[2]), "+v"(sh4[3]), "+v"(rv[0]),
@@ -302,9 +327,11 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const unsigned rg = region + i * 4096;
-        u32x2 rv[4];
+        u32x2 rv[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+        if (RESM != 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("ds_read_b64 %0, %1" : "=v"(rv[g]) : "v"(rg + (((4 * hb + g) ^ (l31 & 7)) << 4)));
+          for (int g = 0; g < 4; ++g) asm volatile("ds_read_b64 %0, %1" : "=v"(rv[g]) : "v"(rg + (((4 * hb + g) ^ (l31 & 7)) << 4)));
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4v sc4, sh4;
@@ -340,22 +367,28 @@ __global__ __launch_bounds__(512, 1) void conv_spw_kernel(const ConvArgs a) {
 }
 
 bool conv_spw_ok(DType dt, bool out_f32, const ConvArgs& a) {
-  return dt == DT_BF16 && !out_f32 && a.Cout % 256 == 0 && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1 && !a.stem && !a.halo && !a.in2 &&
-         a.group_cout == 0 && a.mul_nch == 0 && (a.relu_nch == 0 || a.relu_nch >= a.Cout) && !a.gn_partial && !a.gn_coef && a.Cin % 32 == 0 &&
-         (a.Cin == 128 || a.Cin == 256 || a.Cin == 512) && a.n_ntiles <= 8 && a.res_mode == 1 && a.res != nullptr && (a.out_ld & 7) == 0 && (a.in_ld & 7) == 0 && (a.res_ld & 7) == 0 &&
-         a.pw_desc != nullptr && a.pw_table != nullptr;
+  if (!(dt == DT_BF16 && !out_f32 && a.Cout % 256 == 0 && a.KH == 1 && a.KW == 1 && a.pad == 0 && !a.stem && !a.halo && a.group_cout == 0 && a.mul_nch == 0 &&
+        (a.relu_nch == 0 || a.relu_nch >= a.Cout) && !a.gn_partial && !a.gn_coef && a.n_ntiles <= 8 && (a.out_ld & 7) == 0 && (a.in_ld & 7) == 0 &&
+        a.pw_desc != nullptr && a.pw_table != nullptr))
+    return false;
+  const int K = a.Cin + (a.in2 ? a.Cin2 : 0);
+  if (a.res_mode == 1)  // conv3 + residual of the identity blocks (round 5)
+    return !a.in2 && a.stride == 1 && (K == 128 || K == 256 || K == 512) && a.res != nullptr && (a.res_ld & 7) == 0;
+  if (a.res_mode == 2)  // FPN lateral + top-down add
+    return !a.in2 && a.stride == 1 && K == 512 && a.relu_nch == 0 && a.res != nullptr && (a.res_ld & 7) == 0;
+  if (a.in2)            // conv3 + projection shortcut of the first res3 block: K = 128 + 256, ReLU
+    return a.Cin == 128 && a.Cin2 == 256 && a.stride == 1 && a.relu_nch > 0 && (a.in2_ld & 7) == 0;
+  return K == 512 && a.relu_nch > 0;  // strided conv1 of the first res4 block
 }
 
-template <int K>
+template <int K, int RESM, bool RELU>
 static int launch_spw_k(const ConvArgs& a, int grid, hipStream_t s) {
   static PerDeviceOnce once;
   if (!once.run(current_device(), [] {
-        return hipFuncSetAttribute((const void*)conv_spw_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) == hipSuccess &&
-               hipFuncSetAttribute((const void*)conv_spw_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) == hipSuccess;
+        return hipFuncSetAttribute((const void*)conv_spw_kernel<K, RESM, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, SPW_LDS) == hipSuccess;
       }))
     return -7;
-  if (a.relu_nch > 0) hipLaunchKernelGGL((conv_spw_kernel<K, true>), dim3(grid), dim3(512), SPW_LDS, s, a);
-  else hipLaunchKernelGGL((conv_spw_kernel<K, false>), dim3(grid), dim3(512), SPW_LDS, s, a);
+  hipLaunchKernelGGL((conv_spw_kernel<K, RESM, RELU>), dim3(grid), dim3(512), SPW_LDS, s, a);
   return (int)hipGetLastError();
 }
 
@@ -366,9 +399,18 @@ int launch_conv_spw(const ConvArgs& a, hipStream_t s) {
   const int per = 8 * a.n_ntiles;
   int grid = (n_cu / per) * per;
   if (grid == 0) return -1;
-  if (a.Cin == 128) return launch_spw_k<128>(a, grid, s);
-  if (a.Cin == 256) return launch_spw_k<256>(a, grid, s);
-  if (a.Cin == 512) return launch_spw_k<512>(a, grid, s);
+  const int K = a.Cin + (a.in2 ? a.Cin2 : 0);
+  const bool relu = a.relu_nch > 0;
+  if (a.res_mode == 1) {
+    if (K == 128) return relu ? launch_spw_k<128, 1, true>(a, grid, s) : launch_spw_k<128, 1, false>(a, grid, s);
+    if (K == 256) return relu ? launch_spw_k<256, 1, true>(a, grid, s) : launch_spw_k<256, 1, false>(a, grid, s);
+    if (K == 512) return relu ? launch_spw_k<512, 1, true>(a, grid, s) : launch_spw_k<512, 1, false>(a, grid, s);
+  } else if (a.res_mode == 2) {
+    if (K == 512 && !relu) return launch_spw_k<512, 2, false>(a, grid, s);
+  } else {
+    if (K == 384 && relu) return launch_spw_k<384, 0, true>(a, grid, s);
+    if (K == 512 && relu) return launch_spw_k<512, 0, true>(a, grid, s);
+  }
   return -1;
 }
 
