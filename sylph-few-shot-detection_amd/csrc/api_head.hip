@@ -401,7 +401,6 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   const int bn = N >= 128 ? 128 : (N > 32 ? 64 : 32);
   const int Npad = (N + bn - 1) / bn * bn;
   RET(ensure_logits(c, P, N, true));
-  RET(run_ops(c, P->head_ops, "fcos_head"));
   // the biases, zero-padded to the packed code rows (device copy: the caller's buffer need not outlive this call)
   if (Npad > P->bias_pad_cap) {
     if (P->bias_pad) c->dfree(P->bias_pad);
@@ -411,8 +410,11 @@ int sylph_fcos_head(sylph_ctx* c, const float* cls_conv, const float* cls_bias, 
   }
   P->has_bias = c->cfg.cond_use_bias && cls_bias;
   // one launch: packed codes + zero-padded biases + the -inf padded copy the fused scan reads
+  // (in FRONT of the towers: it depends on the caller's codes only, and at small batches the main stream waits for the bbox tower on the
+  // side stream at the end of the head ops anyway -- behind them it was 5 us of the step's serial tail)
   KCHK(launch_pack_codes(c->dt, cls_conv, N, 256, Npad, P->code_w, P->has_bias ? cls_bias : nullptr, P->bias_pad, P->bias_pad + P->bias_pad_cap, c->stream),
        "pack_codes");
+  RET(run_ops(c, P->head_ops, "fcos_head"));
   P->scan_fused = false; P->logits_stale = false;
   // Many-way episodes (bf16): conv + scan in one pass, the logits never reach HBM (detect.hip: logits_scan_kernel)
   static const int fuse_scan_on = getenv("SYLPH_FUSE_SCAN") ? atoi(getenv("SYLPH_FUSE_SCAN")) : 1;
