@@ -60,14 +60,16 @@ def test_parity_suite_with_halo_mode_forced():
 
 
 def test_parity_suite_with_streaming_residual_conv_everywhere():
-    """SYLPH_CONV_SPW=2 routes EVERY bottleneck conv3 with a same-geometry residual (K 128 / 256 / 512) through conv_spw_kernel (weights
+    """SYLPH_CONV_SPW=2 routes EVERY layer conv_spw_kernel can run through it whatever the launch size -- bottleneck conv3 with a
+    same-geometry residual (K 128 / 256 / 512), and since round 6 conv3 + projection shortcut of the first res3 block (two inputs, the
+    second strided), the stride-2 conv1 of the first res4 block and FPN lateral3 with its nearest-2x top-down add -- (weights
     in registers, A ring, residual and result streamed through the LDS tile buffer by the streaming waves) whatever the launch size --
     ragged batches, partial last tiles, launches of a few tiles: conv2d vs torch, backbone / episode / full-size checks against the
     oracle, and the ulp-level block tests."""
     env = {"SYLPH_CONV_SPW": "2"}
     _rerun(env, "bf16 and (conv2d or backbone_fpn or c3_full_size or full_size_prop)")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
-                        "bottleneck"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+                        "bottleneck or lateral"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
