@@ -230,13 +230,20 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     // two kernels are equal (res4 / res5) or conv_igemm's five co-resident blocks win (res3, K = 128): those stay there.
     // round 5: a same-geometry residual (conv3 of the identity blocks) takes the streaming variant (conv_spw.hip) on the same operands
     static const int spw_on = getenv("SYLPH_CONV_SPW") ? atoi(getenv("SYLPH_CONV_SPW")) : 1;
-    // round 6: three more layers whose weights fit the registers take it -- the strided conv1 of the first res4 block (K 512, no
-    // residual), conv3 + projection shortcut of the first res3 block (K = 128 + 256 from two inputs) and FPN lateral3 (K 512, top-down add)
-    const bool spw_shape = L.Cout % 256 == 0 && L.Cout <= 2048 && bm == 128 && bn == 256 && (spw_on == 2 || (rows + bm - 1) / bm >= 512);  // a block owns whole M tiles: at least two per CU
-    const bool spw_r1 = o.res_mode == 1 && o.res && (L.Cin == 128 || L.Cin == 256 || L.Cin == 512) && o.stride == 1 && !o.in2 && (o.res_ld & 7) == 0;
-    const bool spw_r2 = o.res_mode == 2 && o.res && L.Cin == 512 && o.stride == 1 && !o.in2 && o.relu_nch == 0 && (o.res_ld & 7) == 0;
+    // round 6: two more layers whose weights fit the registers take it -- conv3 + projection shortcut of the first res3 block (K = 128 + 256
+    // from two inputs) and FPN lateral3 (K 512, top-down add): 1 127 -> 1 051 us and 820 -> 722 us at 120 images, equal at 16, slower
+    // at 8 (87.8 vs 77.8 us: 1 050 M tiles over 128 block slots per N tile) -> from 2 048 M tiles on.  (The strided conv1 of the first res4
+    // block, K 512 without a residual, runs on the kernel too -- SYLPH_CONV_SPW=2 -- but never faster than conv_pw: 208 vs 205 us at 120
+    // images, 48 vs 40 at 16.)
+    const long mtiles = (rows + bm - 1) / bm;
+    const bool spw_shape = L.Cout % 256 == 0 && L.Cout <= 2048 && bm == 128 && bn == 256;
+    const bool spw_r1 = o.res_mode == 1 && o.res && (L.Cin == 128 || L.Cin == 256 || L.Cin == 512) && o.stride == 1 && !o.in2 && (o.res_ld & 7) == 0 &&
+                        (spw_on == 2 || mtiles >= 512);  // a block owns whole M tiles: at least two per CU
+    const bool spw_r2 = o.res_mode == 2 && o.res && L.Cin == 512 && o.stride == 1 && !o.in2 && o.relu_nch == 0 && (o.res_ld & 7) == 0 &&
+                        (spw_on == 2 || mtiles >= 2048);
     const bool spw_r0 = o.res_mode == 0 && !o.res && o.relu_nch > 0 &&
-                        ((!o.in2 && L.Cin == 512 && o.stride == 2) || (o.in2 && L.Cin == 384 && o.Cin2 == 256 && o.stride == 1 && (o.in2_ld & 7) == 0));
+                        ((!o.in2 && L.Cin == 512 && o.stride == 2 && spw_on == 2) ||
+                         (o.in2 && L.Cin == 384 && o.Cin2 == 256 && o.stride == 1 && (o.in2_ld & 7) == 0 && (spw_on == 2 || mtiles >= 2048)));
     spw = spw_on && spw_shape && (spw_r1 || spw_r2 || spw_r0);
     const bool pays = (o.res_mode != 1 || spw) && (L.Cout % 256 == 0 || o.stride != 1);
     pw = fits && (pw_on == 2 || spw || (tiles >= 256 && pays));
