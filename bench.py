@@ -60,10 +60,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=120,
-                    help="query images per GPU per step (round 5: 120 -- on one box 2 112-2 132 img/s at 64, 2 228-2 233 at 96, 2 250-2 254 at 120: "
-                         "launch tails; the largest activation, res2's output, stays below the 4-GiB range of the kernels' 32-bit byte offsets "
-                         "up to 124 images -- beyond it the layers that read it fall back to slower kernels: 2 034 img/s at 128)")
+    ap.add_argument("--batch", type=int, default=192,
+                    help="query images per GPU per step.  Round 6: 192 -- the tower launches are 92 tiles per image, so 192 images are exactly 69 "
+                         "rounds of the 256 CUs, and every launch's ramp / tail is amortised over 1.6 x the work: on one box, alternating, "
+                         "2 234-2 235 img/s at 120, 2 251-2 253 at 176, 2 255-2 267 at 192, 2 254-2 255 at 208 (profiles/r6_batch_sweep.txt); "
+                         "from 225 images on conv_igemm refuses res2-sized inputs (31-bit element offsets): a clean error, not a slow path")
     ap.add_argument("--ways", type=int, default=5)
     ap.add_argument("--shots", type=int, default=5)
     ap.add_argument("--height", type=int, default=800)
@@ -234,11 +235,13 @@ def main():
                 step_b()  # synchronous: decode() ends on the count read-back, as the reference loop ends on cuda.synchronize
             torch.cuda.synchronize()
             sweep[f"B{b}"] = round(b * n / (time.perf_counter() - ts), 1)
-        # batches past the former 124-image limit of the 32-bit whole-tensor offsets (round 6: per-image 64-bit bases in bottleneck64[p] and
-        # conv_pw): the HEADLINE protocol (steps in flight), so that the figures compare with `value`
+        # other batch sizes in the HEADLINE protocol (steps in flight), so that the figures compare with `value`: 120 = rounds 5-6's headline
+        # batch (like-for-like with BENCH_r05), 160 = past the former 124-image limit of the 32-bit whole-tensor offsets
         large_batch = {"unit": "images/s", "protocol": f"{args.inflight} steps in flight, 8 timed steps after 3 warm-up steps"}
-        for b in (144, 160):
-            qs = dev_images(b, H, Wd, 7, device)
+        for b in (120, 160):
+            if b == B:
+                continue
+            qs = queries[:b] if b <= B else dev_images(b, H, Wd, 7, device)
 
             def launch_b():
                 eng.preprocess(qs); eng.backbone(); eng.head(cls_conv, cls_bias)
@@ -463,7 +466,7 @@ def baseline_config_legs(args, device, local_rank):
     """Untimed extras (same JSON line): the OTHER BASELINE.json configurations on one GPU, each with its own work count --
       c2_r50_20way_10shot : configs[2]  R-50-FPN, COCO 20 novel classes, 10-shot, batch 16 queries of 800x1333
       c4_r101_866way      : configs[3]  R-101-FPN, LVIS freq + common = 866 classes, 5-shot (4 330 support images per episode),
-                                         120 queries of 800x1333 per step (one rank's share of the 8-GPU job; the code all-gather is not in it; rounds 4-5: 64 per step)
+                                         192 queries of 800x1333 per step (one rank's share of the 8-GPU job; the code all-gather is not in it; rounds 4-5: 64, early round 6: 120 per step)
       c5_roi_encoder_337way: configs[4] ROI-Encoder code generator + CondConvBlock head, LVIS rare = 337 classes, 5-shot, 800x1200 queries
     Per leg: img_s (query steps, two in flight, codes resident), support_img_s (steady-state support batches of 12 classes through
     backbone -> code generator), gflop_per_image = the library's own 2 M N K count over the conv launches of a query step,
@@ -539,18 +542,19 @@ def baseline_config_legs(args, device, local_rank):
         return res
 
     legs = {}
+    leg_batch = int(os.environ.get("SYLPH_BENCH_LEG_BATCH", "192"))  # query images per step of the C4 / C5 legs
     legs["c2_r50_20way_10shot"] = run_leg(make_cfg(), W.synthetic_state_dict(0, depth=50), 16, args.height, args.width, 20, 10, 100, steps=12)
     legs["c2_r50_20way_10shot"]["config"] = "BASELINE configs[2]: R-50-FPN COCO 20 novel classes, 10-shot, batch 16 queries"
     cfg4 = make_cfg()
     cfg4.MODEL.RESNETS.DEPTH = 101
-    legs["c4_r101_866way"] = run_leg(cfg4, W.synthetic_state_dict(0, depth=101), 120, args.height, args.width, 866, 5, 300)
+    legs["c4_r101_866way"] = run_leg(cfg4, W.synthetic_state_dict(0, depth=101), leg_batch, args.height, args.width, 866, 5, 300)
     legs["c4_r101_866way"]["config"] = ("BASELINE configs[3]: R-101-FPN LVISv1 Meta-FCOS, 866-way 5-shot; one rank's query share of the 8-GPU job "
                                         "(the code all-gather over xGMI is not part of a query step)")
     runner = MetaFCOSROIEncoderRunner()
     cfg5 = create_cfg(runner.get_default_cfg(), "sylph://LVISv1-Detection/Meta-FCOS/Meta-FCOS-ROI-Encoder-finetune.yaml", ["MODEL.META_LEARN.EVAL_SHOT", 5])
     sd5 = {}
     sd5.update(W.backbone_state_dict(0, depth=50)); sd5.update(W.head_state_dict(1, num_classes=60)); sd5.update(W.roi_encoder_state_dict(seed=4))
-    legs["c5_roi_encoder_337way"] = run_leg(cfg5, sd5, 120, 800, 1200, 337, 5, 300)
+    legs["c5_roi_encoder_337way"] = run_leg(cfg5, sd5, leg_batch, 800, 1200, 337, 5, 300)
     legs["c5_roi_encoder_337way"]["config"] = ("BASELINE configs[4]: ROI-Encoder code generator + CondConvBlock head (Meta-FCOS-ROI-Encoder-finetune.yaml), "
                                                "LVIS rare 337-way 5-shot, 800x1200 queries; one rank's share of the 4-GPU job")
     return legs
