@@ -302,8 +302,8 @@ def main():
             r = round(b * n / (time.perf_counter() - ts), 1)
             e.close()
             return r
-        fp32_img_s = mode_leg("f32", 8, 3)
-        parity_mode_img_s = mode_leg("f32s", 16, 5)
+        fp32_img_s = mode_leg("f32", 64, 3)
+        parity_mode_img_s = mode_leg("f32s", 64, 4)  # 64 per step: 522 / 560 / 571 / 580 / 585 img/s at 8 / 16 / 32 / 48 / 64 (one box)
     support_leg = None
     if rank == 0 and world == 1 and not args.no_sweep:
         # steady-state SUPPORT path: classes x shots support images of 800x1333 per batch through preprocess ->
@@ -440,7 +440,7 @@ def main():
             out["large_batch"] = large_batch
             out["fp32_img_s"] = fp32_img_s
             out["parity_mode_img_s"] = parity_mode_img_s
-            out["parity_mode"] = {"dtype": "f32s", "img_s": parity_mode_img_s, "batch": 16, "north_star_target_img_s": 300,
+            out["parity_mode"] = {"dtype": "f32s", "img_s": parity_mode_img_s, "batch": 64, "north_star_target_img_s": 300,
                                   "note": "fp32 storage, conv products as three bf16 MFMAs on bf16 hi + lo operand parts; head outputs <= 1e-3 of the "
                                           "fp32 CPU oracle and the oracle's NMS indices at 800x1333 (tests/test_split_mode_gpu.py); the exact-fp32-MFMA "
                                           "mode is fp32_img_s"}
