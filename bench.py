@@ -427,7 +427,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: R-50-FPN 5-way 5-shot, 800x1333 synthetic queries",
                        "batch_per_gpu": B, "steps_in_flight": args.inflight, "ways": N, "shots": S, "image": [H, Wd], "code_scale": args.code_scale,
                        "parallelism": f"dp{world} (queries sharded, codes all-gathered once per episode)",
-                       "detections_last_step": ndet},
+                       "detections_last_step": {"images": len(ndet), "total": sum(ndet), "min": min(ndet), "max": max(ndet)}},
             "images_per_sec_per_gpu": round(value / world, 2),
             "tflops_sustained_per_gpu": round(GFLOP_PER_IMAGE_TOTAL * value / world / 1e3, 1),
             "episode_setup": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in setup.items()},
