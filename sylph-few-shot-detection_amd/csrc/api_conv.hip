@@ -351,7 +351,13 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   // 64-row tiles are what conv_pick_tile gives a launch of fewer than 1024 128-row blocks, i.e. one that cannot hide the round trip of
   // a K-slice behind co-resident blocks: those walk K through TWO LDS stages (the next slice's loads under the current MFMAs).
   // Measured (tools/sweep_small_batches.py): batch 1 574 -> 606 img/s, batch 2 908 -> 931, batch 8 1 643 -> 1 665.
-  if (nbuf2_on && dt == DT_BF16 && !hpipe && !halo && !pw && BM == 64) a.nbuf2 = 1;
+  // Round 6: THREE stages (two slices in flight, 72 KiB: two blocks per CU) for launches of at most 400 tiles -- about one block per CU,
+  // where nothing else hides a slice's round trip: batch 1 622 -> 652 img/s, batch 2 944 -> 962, batch 4-16 +0.3 ... 0.8 %
+  // (profiles/r6_small_batch.md; thresholds 320 / 400 / 512 equal, 256 half the gain, 600 -5 % at batch 4: the launches of 400-600
+  // tiles want three blocks per CU).  Four stages (96 KiB, one block per CU) add nothing on top.  SYLPH_CONV_NBUF3_MAX=0: two stages.
+  static const int nbuf3_max = getenv("SYLPH_CONV_NBUF3_MAX") ? atoi(getenv("SYLPH_CONV_NBUF3_MAX")) : 400;
+  if (nbuf2_on && dt == DT_BF16 && !hpipe && !halo && !pw && BM == 64)
+    a.nbuf2 = (long)g.n_mtiles * (L.Cout_pad / BN) <= nbuf3_max ? 3 : 2;
   // ---- split K (small batches: SylphPredictor / the reference's batch-1 query loop, predictor.py:248-274) ------------------------
   // A launch with fewer tiles than CUs walks its whole K range as ONE latency-bound chain per block (load slice -> wait -> MFMA, no
   // co-resident blocks to hide it) while most of the chip idles: res5 conv2 of one 800x1333 image is 96 blocks x 72 slices = 82 us
@@ -366,7 +372,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
     // Where it pays (B = 1 timeline, profiles/r4_timeline_B1.txt): deep K (>= 32 slices: the 3x3 convs of res4 / res5 / FPN P5..P7, the
     // 2048-channel 1x1s) on at most 1.5 tiles per CU.  Every extra launch costs ~9 us of dispatch latency at batch 1 and the fp32
     // planes are 2 x ks times the bf16 output: shallow-K or many-row layers (res3, the 1x1s of res4) lose, so they are not split.
-    int ks = (int)((768 + tiles_all - 1) / tiles_all);  // about three blocks per CU
+    int ks = (int)((512 + tiles_all - 1) / tiles_all);  // two blocks per CU (rounds 4-5: 768; 512 is equal at batch 1 / 4 / 8 and +2 % at batch 2)
     if (ks > nk_slices / 4) ks = nk_slices / 4;          // at least four slices per range
     if (ks > 8) ks = 8;
     const long plane_bytes = rows * (long)L.Cout * 4;
@@ -414,6 +420,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
       b.segs = gs.segs; b.tiles = gs.tiles; b.n_mtiles = gs.n_mtiles;
       b.out = nullptr; b.out_ld = L.Cout; b.res = nullptr; b.res_mode = 0; b.scale = nullptr; b.shift = nullptr; b.relu_nch = 0;
       b.ksplit = ks; b.split_stride = (long long)plane;
+      if (b.nbuf2) b.nbuf2 = 2;  // ks K ranges per tile, two blocks per CU: the two-stage ring (three stages measured equal)
       const float *scl = L.scale, *shf = L.shift;
       const void* resp = o.res_mode == 1 ? o.res : nullptr;
       const int res_ld = o.res_ld, relu_nch = o.relu_nch, Cout = L.Cout, nseg = (int)ss.size();

@@ -75,7 +75,7 @@ struct ConvArgs {
   int pw_rot_mask;            // set by launch_conv_pw
   int ksplit;                 // conv_igemm.hip split K: > 1 = grid.y K ranges, fp32 partial planes in `out` (plane stride split_stride elements)
   long long split_stride;
-  int nbuf2;                  // conv_igemm.hip: double-buffered K loop (small launches, 64-row tiles)
+  int nbuf2;                  // conv_igemm.hip: LDS stages of the K loop of small launches (64-row tiles): 0 = one, 2, 3
 };
 
 // one segment of a split-K finish pass: rows [src_row0, +nrows) of the partial planes -> rows [dst_row0, ..) of the output

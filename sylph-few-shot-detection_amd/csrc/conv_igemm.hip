@@ -410,7 +410,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (SPLIT ? (BM * BN == 128 * 128 ? 3 
     }
   };
 
-  if (NBUF == 1) {
+  if constexpr (NBUF == 1) {
     for (int kt = kt0; kt < kt1; ++kt) {
       const int hoff = ((kh * HW2 + kw) << 8) | ((kh * HPW + kw) & 15);  // halo row offset (and swizzle-key shift) of the tap about to be fetched
       issue(0);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (SPLIT ? (BM * BN == 128 * 128 ? 3 
       compute(0, hoff);
       __syncthreads();
     }
-  } else {
+  } else if constexpr (NBUF == 2) {
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -430,6 +430,30 @@ __global__ __launch_bounds__(WGM * WGN * 64, (SPLIT ? (BM * BN == 128 * 128 ? 3 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+  } else {
+    // Ring of NBUF stages (3; 4 measured equal), NBUF - 1 slices in flight, for launches of about one block per CU: nothing else hides a slice's
+    // round trip there.  Every wave issues LPS loads per slice and vmcnt retires in order: "slice kt has landed" = at most (slices
+    // issued after it) * LPS of this wave's loads outstanding.  The barrier that publishes slice kt also says every wave is done with
+    // slice kt - 1, whose stage the next issue overwrites.  lds_barrier(), not __syncthreads(): its fence would drain the slices in flight.
+    constexpr int LPS = AR + BR;
+    static_assert((NBUF - 2) * LPS <= 63, "vmcnt range");
+    constexpr int W1 = LPS, W2 = 2 * LPS;
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+      if (kt0 + s < kt1) issue(s);
+    int cur = 0, nxt = NBUF - 1;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int after = kt1 - 1 - kt;  // slices issued behind this one (capped at NBUF - 2)
+      if (after == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (after == 1 || NBUF == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2) : "memory");
+      lds_barrier();
+      if (kt + NBUF - 1 < kt1) issue(nxt);
+      compute(cur, 0);
+      cur = cur + 1 == NBUF ? 0 : cur + 1;
+      nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
+    __syncthreads();
   }
 
   // ---- fused epilogue ---------------------------------------------------------------------------
@@ -807,6 +831,16 @@ int launch_conv(DType dt, bool out_f32, const ConvArgs& a_in, int BM, int BN, hi
       return fast ? launch_cfg<bf16_t, bf16_t, 128, 64, 2, 2, 1, true, true>(a, s)
                   : launch_cfg<bf16_t, bf16_t, 128, 64, 2, 2, 1, false, true>(a, s);
     }
+#define SYLPH_IGEMM_RING(NB)                                                                                                                       \
+  do {                                                                                                                                             \
+    const bool fast = !out_f32 && fast_ok(a, BN);                                                                                                  \
+    if (BN == 128) return out_f32 ? launch_cfg<bf16_t, float, 64, 128, 2, 2, NB, false>(a, s)                                                      \
+                                  : (fast ? launch_cfg<bf16_t, bf16_t, 64, 128, 2, 2, NB, true>(a, s) : launch_cfg<bf16_t, bf16_t, 64, 128, 2, 2, NB, false>(a, s)); \
+    return out_f32 ? launch_cfg<bf16_t, float, 64, 64, 2, 2, NB, false>(a, s)                                                                      \
+                   : (fast ? launch_cfg<bf16_t, bf16_t, 64, 64, 2, 2, NB, true>(a, s) : launch_cfg<bf16_t, bf16_t, 64, 64, 2, 2, NB, false>(a, s)); \
+  } while (0)
+    if (a.nbuf2 == 3 && g_nbuf == 1 && BM == 64 && (BN == 128 || BN == 64)) SYLPH_IGEMM_RING(3);
+#undef SYLPH_IGEMM_RING
     if (a.nbuf2 && g_nbuf == 1 && BM == 64 && (BN == 128 || BN == 64)) {
       // small launches (fewer blocks than it takes to hide a slice's round trip by occupancy): two LDS stages, the next slice's loads
       // in flight under the current slice's MFMAs

@@ -183,3 +183,21 @@ def test_fused_backbone_kernels_match_unfused_graph_on_ragged_maps(tmp_path, B, 
         cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
         err = np.abs(a - b).max() / max(1.0, np.abs(b).max())
         assert cos > 0.9995 and err < 0.05, f"level {lvl}: cosine {cos}, max rel err {err}"
+
+
+@pytest.mark.gpu
+def test_three_stage_ring_of_the_small_tiles_is_bit_identical(tmp_path):
+    """conv_igemm's 64-row tiles walk K through three LDS stages in launches of at most 400 tiles (round 6: two slices in flight where
+    nothing else hides a slice's round trip) and through two otherwise (SYLPH_CONV_NBUF3_MAX=0: everywhere).  Same slices, same order,
+    same MFMAs: the batch-1 pyramid (res3..res5, FPN: 264- / 144- / 96-tile launches) must be bit-identical."""
+    outs = {}
+    for name, env_extra in (("three", {}), ("two", {"SYLPH_CONV_NBUF3_MAX": "0"})):
+        path = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _PYRAMID_CHILD, os.path.join(ROOT, "sylph-few-shot-detection_amd"), os.path.join(ROOT, "tests"), path,
+                            "1", "800", "1333"], env=dict(os.environ, **env_extra), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        z = np.load(path)
+        outs[name] = [z[k] for k in z.files]
+    assert len(outs["three"]) == 5
+    for lvl, (a, b) in enumerate(zip(outs["three"], outs["two"])):
+        assert np.isfinite(a).all() and np.array_equal(a, b), f"level {lvl}: {np.abs(a - b).max()}"
