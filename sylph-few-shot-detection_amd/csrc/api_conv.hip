@@ -364,11 +364,17 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   // for 5 GFLOP.  Such launches are split along K into grid.y ranges that write fp32 partial planes; a finish pass adds the planes
   // in plane order (deterministic) and applies the epilogue.  Same rounding points as the unsplit kernel, fp32 summation order differs.
   static const int split_on = getenv("SYLPH_SPLIT_K") ? atoi(getenv("SYLPH_SPLIT_K")) : 1;
+  // Round 6: with three LDS stages in the small tiles (above) the un-split K walk of a launch of ~100-400 tiles is as fast as split + finish
+  // and saves the finish launch: only launches of at most 64 tiles (FPN P6 / P7, the small heads) are still split.  Rounds 4-5 split up to
+  // 384 tiles (>= 32 slices) / 768 (>= 64 slices).  Batch 1 / 2 / 4 / 8: 655 / 985 / 1 333 / 1 701 -> 676 / 1 031 / 1 354 / 1 705 img/s together
+  // with the 64 x 64 tiles of conv_pick_tile (profiles/r6_small_batch.md); 13 of the 17 finish launches of a batch-1 step are gone.
+  static const int split_t1 = getenv("SYLPH_SPLIT_T1") ? atoi(getenv("SYLPH_SPLIT_T1")) : 64;
+  static const int split_t2 = getenv("SYLPH_SPLIT_T2") ? atoi(getenv("SYLPH_SPLIT_T2")) : 64;
   const int nk_slices = L.KH * L.KW * (L.Cin / 64);
   const long tiles_all = (long)g.n_mtiles * (L.Cout_pad / BN);
   if (split_on && dt == DT_BF16 && !hpipe && !halo && !pw && !of32 && !o.in2 && !o.stem && !o.want_gn && !o.gn_coef && o.group_cout == 0 &&
       o.mul_nch == 0 && o.cout_override < 0 && L.Cout == L.Cout_pad && (o.relu_nch == 0 || o.relu_nch >= L.Cout) && o.res_mode != 2 &&
-      (o.res_mode == 0 || (o.res_ld & 7) == 0) && L.Cin % 64 == 0 && ((nk_slices >= 32 && tiles_all <= 384) || (nk_slices >= 64 && tiles_all < 768) || (split_on == 2 && nk_slices >= 8))) {
+      (o.res_mode == 0 || (o.res_ld & 7) == 0) && L.Cin % 64 == 0 && ((nk_slices >= 32 && tiles_all <= split_t1) || (nk_slices >= 64 && tiles_all < split_t2) || (split_on == 2 && nk_slices >= 8))) {
     // Where it pays (B = 1 timeline, profiles/r4_timeline_B1.txt): deep K (>= 32 slices: the 3x3 convs of res4 / res5 / FPN P5..P7, the
     // 2048-channel 1x1s) on at most 1.5 tiles per CU.  Every extra launch costs ~9 us of dispatch latency at batch 1 and the fp32
     // planes are 2 x ks times the bf16 output: shallow-K or many-row layers (res3, the 1x1s of res4) lose, so they are not split.

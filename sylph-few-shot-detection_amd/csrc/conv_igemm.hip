@@ -789,6 +789,10 @@ void conv_pick_tile(int rows_total, int cout, int ntaps, int* BM, int* BN) {
   if (bn != 32) {
     const long blocks128 = (long)((rows_total + 127) / 128) * ((cout + bn - 1) / bn);
     if (blocks128 < 1024) bm = 64;
+    // Round 6: 64 x 64 tiles when even the 64 x 128 grid leaves a third of the CUs idle (<= 160 tiles: res4 / res5 of one 800 x 1333
+    // image): twice the blocks, half the weight stage per block.  From 264 tiles on (res3 at batch 1, res4 at batch 2) measured slower.
+    static const int bn64_max = getenv("SYLPH_CONV_BN64_MAX") ? atoi(getenv("SYLPH_CONV_BN64_MAX")) : 160;
+    if (bm == 64 && bn == 128 && cout % 64 == 0 && (long)((rows_total + 63) / 64) * (cout / 128) <= bn64_max) bn = 64;
   }
 #ifdef SYLPH_ABLATE
   if (const char* f = getenv("SYLPH_CONV_FORCE_BM")) {  // tuning knob

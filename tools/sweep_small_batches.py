@@ -10,7 +10,7 @@ from sylph_amd.engine import Engine
 eng = Engine(bench.make_cfg(), dtype="bf16"); eng.load_state_dict(W.synthetic_state_dict(0, depth=50))
 codes = W.synthetic_codes(5, seed=4, scale=3.0); cw, cb = codes["cls_conv"].cuda(), codes["cls_bias"].cuda()
 out = []
-for b in (1, 2, 4, 8, 16):
+for b in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 2, 4, 8, 16)):
     q = bench.dev_images(b, 800, 1333, 7, torch.device("cuda"))
     def step():
         eng.preprocess(q); eng.backbone(); eng.head(cw, cb); return eng.decode()
