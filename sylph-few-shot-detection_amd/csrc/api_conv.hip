@@ -357,7 +357,7 @@ int add_conv(sylph_ctx* c, std::vector<OpFn>& ops, const ConvLayer& L, const voi
   // tiles want three blocks per CU).  Four stages (96 KiB, one block per CU) add nothing on top.  SYLPH_CONV_NBUF3_MAX=0: two stages.
   static const int nbuf3_max = getenv("SYLPH_CONV_NBUF3_MAX") ? atoi(getenv("SYLPH_CONV_NBUF3_MAX")) : 400;
   if (nbuf2_on && dt == DT_BF16 && !hpipe && !halo && !pw && BM == 64)
-    a.nbuf2 = (long)g.n_mtiles * (L.Cout_pad / BN) <= nbuf3_max ? 3 : 2;
+    a.nbuf2 = (long)g.n_mtiles * (L.Cout_pad / BN) <= nbuf3_max ? 3 : 2;  // (deep-K launches of up to 640 tiles on three stages: batch 4 / 8 -3 %)
   // ---- split K (small batches: SylphPredictor / the reference's batch-1 query loop, predictor.py:248-274) ------------------------
   // A launch with fewer tiles than CUs walks its whole K range as ONE latency-bound chain per block (load slice -> wait -> MFMA, no
   // co-resident blocks to hide it) while most of the chip idles: res5 conv2 of one 800x1333 image is 96 blocks x 72 slices = 82 us
