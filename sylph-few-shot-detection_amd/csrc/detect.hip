@@ -861,6 +861,12 @@ int launch_decode(const DecodeCfg& cfg, const DecodeSeg* segs_dev, int nseg, int
     // locations would be half a round of the block, and 84 000 such blocks a dispatch-bound launch)
     const int groups = (cfg.num_classes + 3) / 4;
     int rows_per_block = (4096 + groups - 1) / groups;
+    // small batches (round 6): at 2 048 locations per block one 800 x 1333 image is 13 blocks (23 us); aim at ~512 blocks instead
+    // (the order of the candidate buffer is irrelevant, see the kernel).  max_nloc is the P3 level: a pyramid is ~4/3 of it per image
+    static const int scan_blocks = getenv("SYLPH_SCAN_BLOCKS") ? atoi(getenv("SYLPH_SCAN_BLOCKS")) : 512;  // 0: the 2 048-location blocks everywhere
+    const long est_rows = (long)max_nloc * B * 4 / 3;
+    const int rpb_small = scan_blocks > 0 ? (int)((est_rows / scan_blocks + 63) / 64 * 64) : rows_per_block;
+    if (rpb_small < rows_per_block) rows_per_block = rpb_small;
     if (rows_per_block < SCAN_ROWS) rows_per_block = SCAN_ROWS;
     dim3 g1((max_nloc + rows_per_block - 1) / rows_per_block, nseg);
     // the scan reads the logits 16 bytes at a time: rows are padded to a multiple of 32 classes by ensure_logits()
