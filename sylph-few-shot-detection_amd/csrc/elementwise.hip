@@ -293,7 +293,30 @@ __global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const GnSeg*
   const int g = threadIdx.x % ngroups, sub = threadIdx.x / ngroups, nsub = 1024 / ngroups;
   __shared__ double sh[1024 * 3];
   double N = 0.0, M = 0.0, Q = 0.0;
-  for (int t = sub; t < sg.ntiles; t += nsub) {
+  // the chain's first PF partials are fetched up front (one memory round trip instead of one per link: a 140-tile P3 segment is 5 links
+  // per chain, and at small batches this launch sits on the critical path between two tower layers); same links, same order
+  constexpr int PF = 8;
+  float pn[PF], pm[PF], pq[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int t = sub + i * nsub;
+    pn[i] = 0.f; pm[i] = 0.f; pq[i] = 0.f;
+    if (t < sg.ntiles) {
+      const float* p = partial + ((size_t)(sg.tile0 + t) * ngroups + g) * 3;
+      pn[i] = p[0]; pm[i] = p[1]; pq[i] = p[2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const double nb = pn[i], mb = pm[i], qb = pq[i];
+    if (nb > 0.0) {  // (a link past the segment's end carries n = 0, like an empty tile)
+      const double nn = N + nb, delta = mb - M;
+      M += delta * (nb / nn);
+      Q += qb + delta * delta * (N * nb / nn);
+      N = nn;
+    }
+  }
+  for (int t = sub + PF * nsub; t < sg.ntiles; t += nsub) {
     const float* p = partial + ((size_t)(sg.tile0 + t) * ngroups + g) * 3;
     const double nb = p[0], mb = p[1], qb = p[2];
     if (nb > 0.0) {
