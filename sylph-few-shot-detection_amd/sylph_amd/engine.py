@@ -470,12 +470,12 @@ class Engine:
         cur = torch.cuda.current_stream(self.device)
         if cur != stream:
             cur.wait_stream(stream)
-        res = []
-        for i in range(B):
-            n = cnt[i]
-            res.append({"pred_boxes": boxes[i, :n], "scores": scores[i, :n], "pred_classes": classes[i, :n],
-                        "fpn_levels": levels[i, :n], "locations": locs[i, :n], "cand_index": cand[i, :n]})
-        return res
+        # B x 6 views: one unbind per tensor + one narrow per view (boxes[i, :n] is two indexing calls per view: 43 -> 19 us per image
+        # of host time on the critical path of a synchronous step)
+        nar = torch.Tensor.narrow
+        cols = [[nar(r, 0, 0, n) for r, n in zip(t.unbind(0), cnt)] for t in (boxes, scores, classes, levels, locs, cand)]
+        keys = ("pred_boxes", "scores", "pred_classes", "fpn_levels", "locations", "cand_index")
+        return [dict(zip(keys, vals)) for vals in zip(*cols)]
 
     # ---- support path -------------------------------------------------------------------------------
     def codegen(self, boxes: torch.Tensor) -> torch.Tensor:
