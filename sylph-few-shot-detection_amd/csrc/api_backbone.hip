@@ -226,7 +226,7 @@ int build_backbone(sylph_ctx* c, Plan* P) {
   // lateral3, output3} -- so the first one runs on the context's side stream between a fork and a join (as the bbox tower does,
   // api_head.hip); large batches keep one stream.
   static const int fpn_two_on = getenv("SYLPH_HEAD_STREAMS") ? atoi(getenv("SYLPH_HEAD_STREAMS")) : 1;
-  const bool fpn_two = fpn_two_on == 2 || (fpn_two_on == 1 && (size_t)B * P->Ltot <= (size_t)8 * 22400);
+  const bool fpn_two = fpn_two_on == 2 || (fpn_two_on == 1 && (size_t)B * P->Ltot <= (size_t)32 * 22400);  // (round 6: 32 images, as the head)
   if (fpn_two && !c->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

@@ -155,7 +155,9 @@ int build_head(sylph_ctx* c, Plan* P) {
     // four such launches -> the bbox tower (+ its prediction pass) runs on a second stream between a fork and a join event, the cls
     // tower stays on the caller's stream.  Large batches fill the chip for many rounds per launch: one stream (measured equal).
     static const int two_on = getenv("SYLPH_HEAD_STREAMS") ? atoi(getenv("SYLPH_HEAD_STREAMS")) : 1;
-    two_streams = two_on == 2 || (two_on == 1 && rows <= (size_t)8 * 22400);
+    // Round 6: up to 32 full-size images (was 8): the two towers' launches of one layer share the last partial round of blocks -- batch 12
+    // 1 737 -> 1 806 img/s, batch 16 / 24 / 32 +1 %, 48 ... 192 equal (profiles/r6_small_batch.md)
+    two_streams = two_on == 2 || (two_on == 1 && rows <= (size_t)32 * 22400);
     if (two_streams && !c->side_stream) {
       HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
