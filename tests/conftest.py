@@ -11,6 +11,17 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The CPU oracle (torch, fp32) is what most of the suite's wall time goes to.  On a many-core host whose container owns only a share of
+# the cores, torch's default thread count (every core it sees) oversubscribes: the bench measured the oracle 4 x slower at 128 threads
+# than at 32 on such a box.  Cap the threads of this process and, through the environment, of the test children (forced-variant reruns).
+try:
+    _ncpu = len(os.sched_getaffinity(0))
+except AttributeError:
+    _ncpu = os.cpu_count() or 1
+_nthreads = str(max(1, min(32, _ncpu)))
+os.environ.setdefault("OMP_NUM_THREADS", _nthreads)
+os.environ.setdefault("MKL_NUM_THREADS", _nthreads)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
