@@ -96,6 +96,18 @@ def test_parity_suite_with_pointwise_kernel_everywhere():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_parity_suite_with_small_tiles_on_three_stages_everywhere():
+    """Round 6's small-launch forms on EVERY launch that takes conv_igemm's 64-row tiles, whatever its size: 64 x 64 tiles instead of
+    64 x 128 (SYLPH_CONV_BN64_MAX) walking K through three LDS stages (SYLPH_CONV_NBUF3_MAX), with the pointwise / streaming kernels
+    off so that the 1x1 layers come this way too, K never split (SYLPH_SPLIT_K=0): conv2d vs torch, backbone / head / episode vs the
+    oracle, the full-size checks, and the ulp-level block tests."""
+    env = {"SYLPH_CONV_BN64_MAX": "100000000", "SYLPH_CONV_NBUF3_MAX": "100000000", "SYLPH_CONV_PW": "0", "SYLPH_CONV_SPW": "0", "SYLPH_SPLIT_K": "0"}
+    _rerun(env, "bf16 and (conv2d or backbone_fpn or head or episode or c3_full_size or full_size_prop)")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_bf16_pinned_gpu.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "bottleneck"], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_parity_suite_with_split_k_and_two_streams_forced():
     """SYLPH_SPLIT_K=2 splits EVERY eligible bf16 conv_igemm launch along K (fp32 partial planes + splitk_finish_kernel), whatever its
     tile count or depth -- 1x1 and 3x3, with and without a same-geometry residual, strided -- and SYLPH_HEAD_STREAMS=2 always runs the
