@@ -13,12 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # The CPU oracle (torch, fp32) is what most of the suite's wall time goes to.  On a many-core host whose container owns only a share of
 # the cores, torch's default thread count (every core it sees) oversubscribes: the bench measured the oracle 4 x slower at 128 threads
-# than at 32 on such a box.  Cap the threads of this process and, through the environment, of the test children (forced-variant reruns).
+# than at 32 on such a box, and fastest at 16.  Cap the threads of this process and, through the environment, of the test children (forced-variant reruns).
 try:
     _ncpu = len(os.sched_getaffinity(0))
 except AttributeError:
     _ncpu = os.cpu_count() or 1
-_nthreads = str(max(1, min(32, _ncpu)))
+_nthreads = str(max(1, min(16, _ncpu)))  # 16: 253 s for the GPU suite, 32: 283 s, torch default (128): 530-709 s
 os.environ.setdefault("OMP_NUM_THREADS", _nthreads)
 os.environ.setdefault("MKL_NUM_THREADS", _nthreads)
 
