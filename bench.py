@@ -654,7 +654,7 @@ def parity_bf16(sd, queries, cls_conv, cls_bias, dets):
     those.  The oracle is the checker here, never the thing measured."""
     from oracle import episode as E
     codes = {"cls_conv": cls_conv.cpu(), "cls_bias": cls_bias.cpu()}
-    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))  # (the oracle is fastest at 16 threads on the 256-CPU boxes)
     matched, total, dmax = 0, 0, 0.0
     with torch.no_grad():
         for q, d in zip(queries, dets):
